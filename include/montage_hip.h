@@ -1,0 +1,179 @@
+/*
+ * montage_hip.h -- C ABI of libmontage_hip.so, the MI355X (gfx950) native code
+ * behind the MontageGAN / StyleGAN2 `torch_utils.ops` plugin boundary.
+ *
+ * Every entry point takes plain device pointers, sizes, strides and a HIP
+ * stream handle (passed as void*; NULL = the null stream).  No torch types
+ * cross this boundary.  All functions return 0 on success and a negative
+ * MG_E_* code on failure; mg_last_error() then holds a message whose text
+ * mirrors the TORCH_CHECK string of the reference entry point it replaces.
+ * Nothing here allocates, frees, copies to the host or synchronises: every
+ * call enqueues kernels on `stream` and returns (graph-capture safe).
+ *
+ * Reference interfaces replaced (paths relative to the reference tree):
+ *   mg_upfirdn2d            <- upfirdn2d_plugin.upfirdn2d
+ *                              montage_gan/torch_utils/ops/upfirdn2d.cpp:16-94,
+ *                              kernels upfirdn2d.cu:29-200, params upfirdn2d.h:14-40
+ *   mg_bias_act             <- bias_act_plugin.bias_act
+ *                              montage_gan/torch_utils/ops/bias_act.cpp:32-90,
+ *                              kernel bias_act.cu:23-147, params bias_act.h:12-32
+ *   mg_fma_bias_act*        <- fma.fma followed by bias_act.bias_act as called by
+ *                              SynthesisLayer (training/networks.py:86-88,311-313),
+ *                              fused into one HBM round trip
+ *   mg_alpha_composite_*    <- custom_utils/image_utils.py:112-163
+ *                              (alpha_composite_pytorch, default branch)
+ *   mg_translate_sample_*   <- fukuwarai/networks.py:246-255 (STNv2c:
+ *                              affine_grid + grid_sample on a pure translation,
+ *                              with the +1/-1 workaround folded in as `shift`)
+ *   mg_filtered_lrelu       <- named by the north star; absent upstream;
+ *                              defined as upfirdn2d(up) -> bias_act(lrelu) -> upfirdn2d(down)
+ */
+#ifndef MONTAGE_HIP_H_
+#define MONTAGE_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_ABI_VERSION 1
+
+/* element types of activation tensors */
+enum { MG_F32 = 0, MG_F16 = 1, MG_BF16 = 2, MG_F64 = 3 };
+
+/* error codes */
+enum {
+    MG_OK = 0,
+    MG_E_ARG = -1,     /* argument check failed (message in mg_last_error) */
+    MG_E_LAUNCH = -2,  /* hipLaunchKernel / hipGetLastError failed */
+    MG_E_NODEV = -3    /* no gfx950 device / runtime not initialised */
+};
+
+/* kernel ids for mg_launch_count / mg_prof_* */
+enum {
+    MG_K_UPFIRDN2D_GENERIC = 0,
+    MG_K_UPFIRDN2D_TILED = 1,
+    MG_K_BIAS_ACT = 2,
+    MG_K_FMA_BIAS_ACT = 3,
+    MG_K_ALPHA_COMPOSITE_FWD = 4,
+    MG_K_ALPHA_COMPOSITE_BWD = 5,
+    MG_K_TRANSLATE_FWD = 6,
+    MG_K_TRANSLATE_BWD_INPUT = 7,
+    MG_K_TRANSLATE_BWD_SHIFT = 8,
+    MG_K_FILTERED_LRELU = 9,
+    MG_K_COUNT = 16
+};
+
+int         mg_abi_version(void);
+const char* mg_last_error(void);               /* thread-local, never NULL */
+uint64_t    mg_launch_count(int kernel_id);    /* kernels enqueued since load */
+
+/* ---- per-kernel timing (HIP events on the launch stream) -------------------
+ * mg_prof_enable(1) makes every launch of the listed kernels record a
+ * hipEvent pair on its own stream; mg_prof_collect() synchronises those events
+ * and returns, per kernel id, the launch count, the summed device time (ms) and
+ * the summed algorithmic bytes ((numel_in + numel_out) * sizeof(T)).
+ * Used only by bench.py and the profiling tests; off by default.            */
+int mg_prof_enable(int on);
+int mg_prof_collect(int kernel_id, uint64_t* launches, double* ms, double* bytes);
+int mg_prof_reset(void);
+
+/* ---- upfirdn2d -------------------------------------------------------------
+ * y[n,c,oy,ox] = gain * sum_{ky,kx} xup_pad[n,c, oy*downy+ky, ox*downx+kx] * ft[ky,kx]
+ * ft = f flipped in both axes unless `flip` (upfirdn2d.cu:66-67,125-126).
+ * Sizes/strides are in ELEMENTS, order {N, C, H, W}; any strides (NCHW, NHWC,
+ * sliced views) are accepted.  The caller computes
+ *   out_w = (in_w*upx + padx0 + padx1 - f_w + downx) / downx   (upfirdn2d.cpp:32)
+ * and passes it in y_size; only pad*0 enters the kernel, as upstream.
+ * f is always float32 [f_h, f_w] on the same device.  Pads may be negative.   */
+int mg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                 const int32_t x_size[4], const int64_t x_stride[4],
+                 const int32_t f_size[2], const int64_t f_stride[2],
+                 const int32_t y_size[4], const int64_t y_stride[4],
+                 int upx, int upy, int downx, int downy,
+                 int padx0, int pady0, int flip, float gain, void* stream);
+
+/* Integer index path only (the part that must be bit exact): for each output
+ * coordinate o in [0, out_size) writes {in0, count, filter0} as computed on the
+ * DEVICE by the same code the kernels use (upfirdn2d.cu:43-48, 60-65).
+ * `table` is device memory, int32[out_size*3].                                */
+int mg_upfirdn2d_index_table(int32_t* table, int out_size, int in_size,
+                             int up, int down, int pad0, int filter_size,
+                             int flip, void* stream);
+
+/* ---- bias_act --------------------------------------------------------------
+ * grad 0: y  = clamp(act(x + b) * gain)
+ * grad 1: dx = dy(x) * act'(.) * gain, zero where |yref| >= clamp
+ * grad 2: second-order term (bias_act.cu:54-142).
+ * b/xref/yref/dy may be NULL.  size_x elements, dense; b index is
+ * (i / step_b) % size_b (bias_act.cu:44).  act = 1..9 (bias_act.py:26-42),
+ * clamp < 0 disables clamping.                                                */
+int mg_bias_act(const void* x, const void* b, const void* xref, const void* yref,
+                const void* dy, void* y, int dtype, int grad, int act,
+                float alpha, float gain, float clamp,
+                int64_t size_x, int32_t size_b, int64_t step_b, void* stream);
+
+/* ---- fused modulated-conv epilogue ----------------------------------------
+ * y = clamp(act(x * d[n,c] + noise[h,w] * noise_gain + b[c]) * gain), NCHW
+ * contiguous; d (float32 [N,C]), noise (float32 [H*W]) and b may each be NULL.
+ * One read and one write of x instead of the three round trips of
+ * fma.fma + bias_act.bias_act (training/networks.py:86-88, 311-313).
+ * mg_fma_bias_act_bwd: dx_pre = dy * act'(yref) * gain masked by the clamp
+ * (this is d/d(pre-activation)); dx = dx_pre * d[n,c]; writes dx and, when
+ * `dpre` is non NULL, dx_pre itself (needed for d(d), d(noise), d(b) sums).    */
+int mg_fma_bias_act(const void* x, const float* d, const float* noise, const void* b,
+                    void* y, int dtype, int act, float alpha, float gain, float clamp,
+                    float noise_gain, int32_t n, int32_t c, int32_t hw, void* stream);
+int mg_fma_bias_act_bwd(const void* dy, const void* yref, const float* d,
+                        void* dx, void* dpre, int dtype, int act, float alpha,
+                        float gain, float clamp, int32_t n, int32_t c, int32_t hw,
+                        void* stream);
+
+/* ---- alpha composite -------------------------------------------------------
+ * x: [B, L, 4, H, W] contiguous (RGB + alpha, values nominally in [0,1]);
+ * y: [B, 4, H, W].  canvas = layer 0; for l = 1..L-1: canvas = layer_l OVER canvas
+ *   a_o = a1 + a2*(1-a1);  c_o = nan_to_num((c1*a1 + c2*a2*(1-a1)) / a_o)
+ * (image_utils.py:129-134,143-147).  nan_to_num: NaN->0, +/-inf->+/-FLT_MAX.
+ * Backward follows the autograd chain of those ops literally, including the
+ * NaN that torch produces where a_o == 0 (0 * inf), unless safe_grad != 0, in
+ * which case those pixels receive a zero gradient.  L <= 16.                  */
+int mg_alpha_composite_fwd(const void* x, void* y, int dtype,
+                           int32_t b, int32_t l, int32_t h, int32_t w, void* stream);
+int mg_alpha_composite_bwd(const void* x, const void* dy, void* dx, int dtype,
+                           int32_t b, int32_t l, int32_t h, int32_t w,
+                           int safe_grad, void* stream);
+
+/* ---- translate sample (STN) -------------------------------------------------
+ * x: [M, C, H, W] contiguous, t: float32 [M, 2] = (dx, dy) in normalised
+ * [-1,1] units.  y = grid_sample(x + shift, affine_grid([[1,0,dx],[0,1,dy]]),
+ * bilinear, zeros, align_corners=False) - shift   (fukuwarai/networks.py:246-255;
+ * shift = 1 for STNv2c, 0 for STNv2b).  bwd_input: dx (a gather, no atomics);
+ * bwd_shift: dt[M,2] float32, MUST be zero-filled by the caller (atomic adds). */
+int mg_translate_sample_fwd(const void* x, const float* t, void* y, int dtype,
+                            int32_t m, int32_t c, int32_t h, int32_t w,
+                            float shift, void* stream);
+int mg_translate_sample_bwd_input(const void* dy, const float* t, void* dx, int dtype,
+                                  int32_t m, int32_t c, int32_t h, int32_t w,
+                                  void* stream);
+int mg_translate_sample_bwd_shift(const void* x, const void* dy, const float* t,
+                                  float* dt, int dtype,
+                                  int32_t m, int32_t c, int32_t h, int32_t w,
+                                  float shift, void* stream);
+
+/* ---- filtered_lrelu (additive) -----------------------------------
+ * y = upfirdn2d(clamp(lrelu(upfirdn2d(x + b[c], fu, up, pad) , alpha) * gain), fd, down)
+ * NCHW contiguous, separable-or-not filters given as dense float32 2-D arrays.
+ * The intermediate lives in LDS only.  up, down in {1,2}.                     */
+int mg_filtered_lrelu(const void* x, const void* b, const float* fu, const float* fd,
+                      void* y, int dtype,
+                      int32_t n, int32_t c, int32_t in_h, int32_t in_w,
+                      int32_t out_h, int32_t out_w,
+                      int32_t fu_h, int32_t fu_w, int32_t fd_h, int32_t fd_w,
+                      int up, int down, int padx0, int pady0,
+                      float alpha, float gain, float clamp, int flip, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONTAGE_HIP_H_ */

@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own CPU code.
+
+Runs ONLY in the authoring container (needs /root/reference); the GPU box never
+sees the reference.  It imports the reference's Python (`impl='ref'` paths run
+because tensors are on the CPU), feeds it seeded inputs, and stores inputs +
+outputs as small .npz files plus a JSON manifest per family.  Nothing of the
+reference's source text is written anywhere: fixtures are arrays and scalars.
+
+    python tests/golden/make_golden.py            # (re)writes tests/golden/*.npz
+
+`torchvision` is not installed here; `custom_utils.image_utils` imports four
+names from it at module import time (image_utils.py:7-8) that none of the
+functions exercised below use.  An empty placeholder module is registered so
+that the import statement passes; it implements nothing.
+"""
+import io
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference/montage_gan'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    for name, attrs in (('torchvision', ()), ('torchvision.transforms', ('ToTensor', 'ToPILImage')),
+                        ('torchvision.utils', ('make_grid', 'save_image'))):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for a in attrs:
+                setattr(m, a, None)
+            sys.modules[name] = m
+    import warnings
+    warnings.filterwarnings('ignore')
+
+
+def save(name, arrays, manifest):
+    arrays = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}
+    buf = io.BytesIO()
+    np.savez_compressed(buf, **arrays)
+    with open(os.path.join(OUT, name + '.npz'), 'wb') as fh:
+        fh.write(buf.getvalue())
+    with open(os.path.join(OUT, name + '.json'), 'w') as fh:
+        json.dump(manifest, fh, indent=1)
+    print(f'{name}: {len(arrays)} arrays, {len(buf.getvalue()) / 1024:.0f} KiB, {len(manifest["cases"])} cases')
+
+
+SYM6 = [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.048311742585633,
+        0.4910559419267466, 0.787641141030194, 0.3379294217276218, -0.07263752278646252,
+        -0.021060292512300564, 0.04472490177066578, 0.0017677118642428036, -0.007800708325034148]
+
+
+# ----------------------------------------------------------------------------
+def gen_upfirdn2d():
+    from torch_utils.ops import upfirdn2d as U
+    g = torch.Generator().manual_seed(1234)
+    filters = {
+        'k1331': [1, 3, 3, 1],            # 4 taps -> 4x4 outer product (upfirdn2d.py:114-118)
+        'sym6': SYM6,                     # 12 taps -> separable
+        'k3': [1, 2, 1], 'k5': [1, 4, 6, 4, 1], 'k7': [1, 2, 3, 4, 3, 2, 1],
+        'k2': [1, 1], 'rect': None, 'none': None,
+    }
+    cases, arrays = [], {}
+
+    def add(kind, shape, fname, dtype='float32', memfmt='contiguous', **kw):
+        i = len(cases)
+        x = torch.randn(shape, generator=g, dtype=torch.float64).to(getattr(torch, dtype))
+        if fname == 'rect':      # a non-square, non-symmetric 2-D filter
+            f = torch.randn([3, 5], generator=g)
+        elif fname == 'none':
+            f = None
+        else:
+            f = U.setup_filter(filters[fname], gain=kw.pop('filter_gain', 1))
+        if memfmt == 'channels_last':
+            x = x.contiguous(memory_format=torch.channels_last)
+        xr = x.clone().requires_grad_(True)
+        fn = dict(upfirdn2d=U.upfirdn2d, upsample2d=U.upsample2d, downsample2d=U.downsample2d, filter2d=U.filter2d)[kind]
+        y = fn(xr, f, impl='ref', **kw)
+        dy = torch.randn(y.shape, generator=g, dtype=torch.float64).to(y.dtype)
+        dx, = torch.autograd.grad([y], [xr], [dy])
+        arrays[f'c{i}_x'] = x.float() if dtype == 'float16' else x
+        if f is not None:
+            arrays[f'c{i}_f'] = f
+        arrays[f'c{i}_y'] = y.float() if dtype == 'float16' else y
+        arrays[f'c{i}_dy'] = dy.float() if dtype == 'float16' else dy
+        arrays[f'c{i}_dx'] = dx.float() if dtype == 'float16' else dx
+        cases.append(dict(id=i, kind=kind, shape=list(shape), filter=fname, dtype=dtype, memfmt=memfmt, kwargs=kw,
+                          out_shape=list(y.shape)))
+
+    # The hot-path configurations.
+    add('upfirdn2d', [2, 3, 17, 17], 'k1331', padding=[1, 1, 1, 1], gain=4)            # G conv0 post blur
+    add('upfirdn2d', [2, 3, 16, 16], 'k1331', padding=[2, 2, 2, 2])                    # D conv1 pre blur
+    add('upsample2d', [2, 4, 8, 8], 'k1331')                                           # ToRGB image upsample
+    add('upfirdn2d', [2, 3, 16, 16], 'k1331', down=2, padding=[1, 1, 1, 1])            # D skip downsample
+    add('upsample2d', [2, 3, 9, 8], 'sym6')                                            # ADA separable up
+    add('downsample2d', [2, 3, 18, 16], 'sym6')                                        # ADA separable down
+    # Grid: scaling per axis, paddings incl. negative, flips, gains, odd sizes, filters.
+    for up in (1, 2, [2, 1], [1, 2], 3):
+        for down in (1, 2, [1, 2], [2, 1]):
+            for fname in ('k1331', 'k3'):
+                add('upfirdn2d', [1, 2, 9, 8], fname, up=up, down=down, padding=[2, 1, 0, 3], gain=0.5)
+    for pad in (0, [-1, 2], [3, -2, -1, 4], [5, 5, 5, 5]):
+        for flip in (False, True):
+            add('upfirdn2d', [1, 2, 16, 17], 'k5', padding=pad, flip_filter=flip)
+            add('upfirdn2d', [1, 2, 16, 17], 'rect', up=2, padding=pad, flip_filter=flip, gain=4)
+    for fname in ('k2', 'k7', 'sym6', 'none'):
+        add('filter2d', [2, 2, 8, 9], fname)
+        add('upsample2d', [2, 2, 8, 9], fname, up=2)
+        add('downsample2d', [2, 2, 16, 18], fname, down=2)
+    add('upfirdn2d', [2, 8, 16, 16], 'k1331', memfmt='channels_last', up=2, padding=[2, 1, 2, 1], gain=4)
+    add('upfirdn2d', [2, 8, 16, 16], 'k1331', memfmt='channels_last', down=2, padding=[1, 1, 1, 1])
+    add('upfirdn2d', [2, 3, 16, 16], 'k1331', dtype='float64', up=2, padding=[2, 1, 2, 1], gain=4)
+    add('upsample2d', [1, 2, 8, 8], 'k1331', filter_gain=2.0)
+
+    # Pure-integer table for the bit-exact index claim: for every case the per-axis
+    # (first input sample, tap count) implied by the reference's own definition
+    # (zero-insert, pad/crop, valid FIR, decimate -- upfirdn2d.py:197-220): output o
+    # reads up-sampled/padded positions o*down .. o*down+fsize-1; position j maps to
+    # input (j - pad0)/up when divisible and inside the image.
+    save('upfirdn2d', arrays, dict(cases=cases))
+
+
+# ----------------------------------------------------------------------------
+def gen_bias_act():
+    from torch_utils.ops import bias_act as B
+    g = torch.Generator().manual_seed(4321)
+    cases, arrays = [], {}
+    special = torch.tensor([0.0, -0.0, 1e-4, -1e-4, 0.5, -0.5, 0.49999, 0.50001, 79.0, -79.0, 81.0, -81.0, 41.0, -41.0])
+
+    def add(act, shape, dim, with_b, alpha=None, gain=None, clamp=None, dtype='float32', memfmt='contiguous'):
+        i = len(cases)
+        tdt = getattr(torch, dtype)
+        x = (torch.randn(shape, generator=g, dtype=torch.float64) * 2).to(tdt)
+        flat = x.reshape(-1)
+        flat[:special.numel()] = special.to(tdt)          # boundary values
+        if memfmt == 'channels_last':
+            x = x.contiguous(memory_format=torch.channels_last)
+        b = torch.randn([shape[dim]], generator=g, dtype=torch.float64).to(tdt) * 0.5 if with_b else None
+        xr = x.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True) if b is not None else None
+        y = B.bias_act(xr, br, dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp, impl='ref')
+        dy = torch.randn(y.shape, generator=g, dtype=torch.float64).to(tdt).requires_grad_(True)
+        ins = [xr] + ([br] if br is not None else [])
+        grads = torch.autograd.grad([y], ins, [dy], create_graph=True)
+        dx = grads[0]
+        arrays[f'c{i}_x'], arrays[f'c{i}_y'], arrays[f'c{i}_dy'], arrays[f'c{i}_dx'] = x, y, dy, dx
+        if b is not None:
+            arrays[f'c{i}_b'], arrays[f'c{i}_db'] = b, grads[1]
+        # second order: d/dx and d/d(dy) of sum(dx * ddx)
+        ddx = torch.randn(dx.shape, generator=g, dtype=torch.float64).to(tdt)
+        arrays[f'c{i}_ddx'] = ddx
+        if dx.requires_grad:
+            g2 = torch.autograd.grad([dx], [xr, dy], [ddx], allow_unused=True)
+            arrays[f'c{i}_g2x'] = g2[0] if g2[0] is not None else torch.zeros_like(x)
+            arrays[f'c{i}_g2dy'] = g2[1] if g2[1] is not None else torch.zeros_like(x)
+        cases.append(dict(id=i, act=act, shape=list(shape), dim=dim, with_b=with_b, alpha=alpha, gain=gain,
+                          clamp=clamp, dtype=dtype, memfmt=memfmt))
+
+    for act in B.activation_funcs.keys():
+        add(act, [2, 5, 4, 4], 1, True)
+        add(act, [2, 5, 4, 4], 1, True, clamp=0.5, gain=0.7)
+        add(act, [3, 7], 1, False, alpha=0.1 if act == 'lrelu' else None)
+    add('lrelu', [2, 6, 3, 5], 3, True, clamp=256)
+    add('lrelu', [2, 8, 4, 4], 1, True, clamp=256, memfmt='channels_last')
+    add('linear', [2, 4, 8, 8], 1, True, clamp=256)
+    add('linear', [2, 4, 8, 8], 1, False, gain=float(np.sqrt(0.5)))
+    add('lrelu', [2, 5, 4, 4], 1, True, dtype='float64', clamp=1.0)
+    add('swish', [2, 5, 4, 4], 0, True, dtype='float64')
+    save('bias_act', arrays, dict(cases=cases))
+
+
+# ----------------------------------------------------------------------------
+def gen_conv():
+    from torch_utils.ops import conv2d_resample as CR, upfirdn2d as U, fma as FMA
+    from training import networks as NW
+    g = torch.Generator().manual_seed(777)
+    cases, arrays = [], {}
+    f = U.setup_filter([1, 3, 3, 1])
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g)
+
+    def add_cr(xs, ws, **kw):
+        i = len(cases)
+        x, w = rnd(xs).requires_grad_(True), rnd(ws).requires_grad_(True)
+        y = CR.conv2d_resample(x, w, f=f if kw.pop('use_f', True) else None, **kw)
+        dy = rnd(y.shape)
+        dx, dw = torch.autograd.grad([y], [x, w], [dy])
+        arrays.update({f'c{i}_x': x, f'c{i}_w': w, f'c{i}_y': y, f'c{i}_dy': dy, f'c{i}_dx': dx, f'c{i}_dw': dw})
+        cases.append(dict(id=i, op='conv2d_resample', kwargs=kw, use_f=True))
+
+    add_cr([2, 4, 8, 8], [3, 4, 1, 1], down=2)                       # 1x1 + down
+    add_cr([2, 4, 8, 8], [3, 4, 1, 1], up=2)                         # 1x1 + up
+    add_cr([2, 4, 8, 8], [3, 4, 3, 3], down=2, padding=1)            # blur + strided conv
+    add_cr([2, 4, 8, 8], [3, 4, 3, 3], up=2, padding=1)              # transpose conv + blur
+    add_cr([2, 4, 8, 8], [3, 4, 3, 3], up=2, padding=1, flip_weight=False)
+    add_cr([2, 4, 8, 8], [4, 2, 3, 3], up=2, padding=1, groups=2)
+    add_cr([2, 4, 8, 8], [3, 4, 3, 3], padding=1)                    # plain conv
+    add_cr([2, 4, 8, 8], [3, 4, 3, 3], padding=[1, 0, 2, 1])         # generic fallback
+    add_cr([2, 4, 8, 8], [3, 4, 3, 3], up=2, down=2, padding=1)      # up then down
+
+    def add_mod(up, demod, noise, fused):
+        i = len(cases)
+        x, w, s = rnd([2, 4, 8, 8]).requires_grad_(True), rnd([3, 4, 3, 3]).requires_grad_(True), rnd([2, 4]).requires_grad_(True)
+        res = 8 * up
+        nz = rnd([res, res]) * 0.3 if noise else None
+        y = NW.modulated_conv2d(x=x, weight=w, styles=s, noise=nz, up=up, padding=1, resample_filter=f,
+                                demodulate=demod, flip_weight=(up == 1), fused_modconv=fused)
+        dy = rnd(y.shape)
+        dx, dw, ds = torch.autograd.grad([y], [x, w, s], [dy])
+        arrays.update({f'c{i}_x': x, f'c{i}_w': w, f'c{i}_s': s, f'c{i}_y': y, f'c{i}_dy': dy, f'c{i}_dx': dx,
+                       f'c{i}_dw': dw, f'c{i}_ds': ds})
+        if nz is not None:
+            arrays[f'c{i}_noise'] = nz
+        cases.append(dict(id=i, op='modulated_conv2d', up=up, demodulate=demod, noise=noise, fused=fused))
+
+    for up in (1, 2):
+        for demod in (True, False):
+            for noise in (True, False):
+                for fused in (True, False):
+                    add_mod(up, demod, noise, fused)
+
+    i = len(cases)
+    a, b, c = rnd([2, 3, 4, 4]).requires_grad_(True), rnd([2, 3, 1, 1]).requires_grad_(True), rnd([1, 1, 4, 4]).requires_grad_(True)
+    y = FMA.fma(a, b, c)
+    dy = rnd(y.shape)
+    da, db, dc = torch.autograd.grad([y], [a, b, c], [dy])
+    arrays.update({f'c{i}_a': a, f'c{i}_b': b, f'c{i}_c': c, f'c{i}_y': y, f'c{i}_dy': dy, f'c{i}_da': da,
+                   f'c{i}_db': db, f'c{i}_dc': dc})
+    cases.append(dict(id=i, op='fma'))
+    save('conv', arrays, dict(cases=cases))
+
+
+# ----------------------------------------------------------------------------
+def gen_montage():
+    """alpha composite (image_utils.py:112-163), STN sampling (fukuwarai/networks.py:235-258),
+    layout helpers (image_utils.py:216-243, 316-335)."""
+    from custom_utils import image_utils as IU
+    import torch.nn.functional as F
+    from PIL import Image
+    g = torch.Generator().manual_seed(99)
+    cases, arrays = [], {}
+
+    # (1) the reference's own test images: 9 RGBA layers, centre crop 128x128
+    ldir = '/root/reference/montage_gan/custom_utils/test_data/layers'
+    names = sorted(os.listdir(ldir))
+    lay = np.stack([np.asarray(Image.open(os.path.join(ldir, n)).convert('RGBA'), dtype=np.uint8) for n in names])
+    lay = lay[:, 64:192, 64:192, :].transpose(0, 3, 1, 2).copy()        # [L,4,128,128] uint8
+    x = torch.from_numpy(lay).float() / 255.0
+    y = IU.alpha_composite_pytorch(x.clone())
+    arrays['png_layers_u8'], arrays['png_out'] = lay, y
+    cases.append(dict(id=0, op='alpha_composite', src='png', layers=names))
+
+    # (2) random [0,1] stacks with exact zeros / ones in alpha, forward + backward
+    def comp_case(i, b, l, h, w, lo=0.0, hi=1.0):
+        x = torch.rand([b, l, 4, h, w], generator=g) * (hi - lo) + lo
+        m = torch.rand([b, l, 1, h, w], generator=g)
+        x[:, :, 3:4] = torch.where(m < 0.3, torch.zeros_like(m), torch.where(m > 0.85, torch.ones_like(m), x[:, :, 3:4]))
+        xr = x.clone().requires_grad_(True)
+        y = IU.alpha_composite_pytorch(xr)
+        dy = torch.randn(y.shape, generator=g)
+        dx, = torch.autograd.grad([y], [xr], [dy])
+        arrays.update({f'c{i}_x': x, f'c{i}_y': y, f'c{i}_dy': dy, f'c{i}_dx': dx})
+        cases.append(dict(id=i, op='alpha_composite', src='rand', shape=[b, l, 4, h, w]))
+
+    comp_case(1, 2, 8, 12, 10)
+    comp_case(2, 1, 3, 8, 8)
+    comp_case(3, 2, 9, 6, 7, lo=-0.25, hi=1.25)      # out-of-range values as a generator would emit
+    comp_case(4, 3, 1, 4, 4)                         # single layer = identity
+
+    # (3) STN sampling: translate by (dx, dy), both STNv2b (shift 0) and STNv2c (+1/-1 workaround)
+    def stn_case(i, b, l, c, h, w, shift, scale):
+        x = torch.randn([b, l, c, h, w], generator=g)
+        tr = (torch.rand([b, l, 2], generator=g) * 2 - 1) * scale
+        xr, trr = x.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+        theta = IU.convert_translate_to_2x3(trr).view(-1, 2, 3)
+        x2 = xr.view(-1, c, h, w)
+        grid = F.affine_grid(theta, x2.size(), align_corners=False)
+        y = F.grid_sample(x2 + shift, grid, align_corners=False) - shift
+        dy = torch.randn(y.shape, generator=g)
+        dx, dt = torch.autograd.grad([y], [xr, trr], [dy])
+        arrays.update({f'c{i}_x': x, f'c{i}_t': tr, f'c{i}_theta': theta, f'c{i}_y': y, f'c{i}_dy': dy, f'c{i}_dx': dx,
+                       f'c{i}_dt': dt})
+        cases.append(dict(id=i, op='translate_sample', shape=[b, l, c, h, w], shift=shift))
+
+    stn_case(5, 2, 3, 4, 16, 16, 0.0, 0.5)
+    stn_case(6, 2, 3, 4, 16, 16, 1.0, 0.5)
+    stn_case(7, 1, 2, 4, 12, 20, 1.0, 1.5)           # partly / fully out of frame
+    stn_case(8, 1, 4, 2, 9, 7, 0.0, 0.05)
+
+    # (4) layout helpers
+    lst = [torch.randn([2, 4, s, s], generator=g) for s in (8, 16, 256)]
+    lst_small = [torch.nn.functional.interpolate(t, size=(8, 8)) if t.shape[-1] == 256 else t for t in lst]
+    pe = IU.make_batch_for_pos_estimator([lst_small[0], lst_small[1]], pad_value=-1)
+    arrays['pe_in0'], arrays['pe_in1'], arrays['pe_out_corner'] = lst_small[0], lst_small[1], pe[:, :, :, 112:144, 112:144]
+    arrays['pe_out_shape'] = np.asarray(pe.shape)
+    arrays['pe_out_sum'] = pe.double().sum()
+    cases.append(dict(id=9, op='make_batch_for_pos_estimator', pad_value=-1))
+    save('montage', arrays, dict(cases=cases))
+
+
+if __name__ == '__main__':
+    _import_reference()
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv', 'montage']
+    for w in which:
+        globals()['gen_' + w]()
