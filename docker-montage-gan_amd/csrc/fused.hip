@@ -1,0 +1,285 @@
+// fused.hip -- fusions the plugin API permits without changing what callers compute.
+//
+//  * mg_fma_bias_act / _bwd: the modulated-conv epilogue of SynthesisLayer,
+//      x = fma(x, dcoefs[N,C,1,1], noise[1,1,H,W]) ; x = bias_act(x, b, act, gain, clamp)
+//    (reference training/networks.py:86-88 + 311-313 -> fma.py:16, bias_act.py:71)
+//    as ONE read and ONE write of the activation instead of three round trips.
+//  * mg_filtered_lrelu: upsample-FIR -> bias+lrelu(+clamp) -> downsample-FIR with the
+//    up-sampled intermediate living in LDS only.  Absent upstream; defined as
+//    the composition of the reference's own ops (upfirdn2d -> bias_act -> upfirdn2d).
+#include "mg_common.h"
+#include "mg_act.h"
+
+namespace {
+
+template <class T> struct FbArgs {
+    const T* x; const float* d; const float* noise; const T* b; T* y; T* y2;
+    float alpha, gain, clamp, noise_gain;
+    uint32_t c, hw, total_vec;
+    FastDiv hwv_div, c_div;     // hw/VEC and C
+};
+
+// forward.  One lane = one 16-byte vector inside one (n,c) plane (hw % VEC == 0) or one element.
+template <class T, int A, int VEC>
+__global__ void __launch_bounds__(256) fma_bias_act_fwd_kernel(FbArgs<T> p)
+{
+    struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
+    const BaConst<float> k = {p.alpha, p.gain, p.clamp};
+    const uint32_t hwv = p.hw / VEC;
+    for (uint32_t vi = blockIdx.x * 256u + threadIdx.x; vi < p.total_vec; vi += gridDim.x * 256u) {
+        uint32_t plane = fd_div(vi, p.hwv_div), pv = vi - plane * hwv;
+        V xin = ((const V*)p.x)[vi];
+        float dc = p.d ? p.d[plane] : 1.f;
+        float bb = 0.f;
+        if (p.b) { uint32_t n = fd_div(plane, p.c_div); bb = to_acc<T>(p.b[plane - n * p.c]); }
+        V out;
+        #pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            float v = to_acc<T>(xin.v[e]) * dc;
+            if (p.noise) v += p.noise[pv * VEC + e] * p.noise_gain;
+            // the reference rounds the fma result to T before bias_act reads it back
+            v = to_acc<T>(from_acc<T>(v));
+            out.v[e] = from_acc<T>(ba_eval<float, A>(0, v, bb, 0.f, 0.f, 1.f, k));
+        }
+        ((V*)p.y)[vi] = out;
+    }
+}
+
+// backward.  x := dy, b := yref here.  y = dx = dpre * d[plane], y2 = dpre (optional).
+template <class T, int A, int VEC>
+__global__ void __launch_bounds__(256) fma_bias_act_bwd_kernel(FbArgs<T> p)
+{
+    struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
+    const BaConst<float> k = {p.alpha, p.gain, p.clamp};
+    for (uint32_t vi = blockIdx.x * 256u + threadIdx.x; vi < p.total_vec; vi += gridDim.x * 256u) {
+        uint32_t plane = fd_div(vi, p.hwv_div);
+        V dy = ((const V*)p.x)[vi], yr = ((const V*)p.b)[vi];
+        float dc = p.d ? p.d[plane] : 1.f;
+        V o1, o2;
+        #pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            float g = ba_eval<float, A>(1, to_acc<T>(dy.v[e]), 0.f, 0.f, to_acc<T>(yr.v[e]), 1.f, k);
+            o2.v[e] = from_acc<T>(g);
+            // dx is the gradient through fma of the T-rounded bias_act gradient
+            o1.v[e] = from_acc<T>(to_acc<T>(o2.v[e]) * dc);
+        }
+        ((V*)p.y)[vi] = o1;
+        if (p.y2) ((V*)p.y2)[vi] = o2;
+    }
+}
+
+template <class T, int A>
+void launch_fb(const FbArgs<T>& p0, bool bwd, bool wide, hipStream_t s)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    FbArgs<T> p = p0;
+    int vec = wide ? VEC : 1;
+    p.hwv_div = make_fastdiv(p.hw / vec);
+    p.total_vec = p.total_vec / vec;
+    uint32_t blocks = (p.total_vec + 255u) / 256u;
+    if (blocks > 256u * 16u) blocks = 256u * 16u;
+    if (blocks < 1) blocks = 1;
+    if (!bwd) {
+        if (wide) hipLaunchKernelGGL((fma_bias_act_fwd_kernel<T, A, VEC>), dim3(blocks), dim3(256), 0, s, p);
+        else      hipLaunchKernelGGL((fma_bias_act_fwd_kernel<T, A, 1>), dim3(blocks), dim3(256), 0, s, p);
+    } else {
+        if (wide) hipLaunchKernelGGL((fma_bias_act_bwd_kernel<T, A, VEC>), dim3(blocks), dim3(256), 0, s, p);
+        else      hipLaunchKernelGGL((fma_bias_act_bwd_kernel<T, A, 1>), dim3(blocks), dim3(256), 0, s, p);
+    }
+}
+
+template <class T>
+int dispatch_fb(const FbArgs<T>& p, int act, bool bwd, bool wide, hipStream_t s)
+{
+    switch (act) {
+    case 1: launch_fb<T, 1>(p, bwd, wide, s); return MG_OK;
+    case 2: launch_fb<T, 2>(p, bwd, wide, s); return MG_OK;
+    case 3: launch_fb<T, 3>(p, bwd, wide, s); return MG_OK;
+    case 4: launch_fb<T, 4>(p, bwd, wide, s); return MG_OK;
+    case 5: launch_fb<T, 5>(p, bwd, wide, s); return MG_OK;
+    case 6: launch_fb<T, 6>(p, bwd, wide, s); return MG_OK;
+    case 7: launch_fb<T, 7>(p, bwd, wide, s); return MG_OK;
+    case 8: launch_fb<T, 8>(p, bwd, wide, s); return MG_OK;
+    }
+    mg_set_error("fma_bias_act: activation %d needs the pre-activation input and is not fusable", act);
+    return MG_E_ARG;
+}
+
+// ---------------------------------------------------------------------------
+// filtered_lrelu: one workgroup = one (plane, output tile).  Runtime filter sizes
+// (<= FL_MAXF taps per axis), up/down in {1,2}.  Three LDS stages:
+//   s_in  : input footprint (+bias), fp32, zero outside the image
+//   s_mid : up-sampled, filtered, activated intermediate (the tensor that never hits HBM)
+//   out   : decimating FIR of s_mid, straight to global
+constexpr int FL_TW = 32, FL_TH = 32, FL_MAXF = 12;
+constexpr int FL_MIDW = FL_TW * 2 + FL_MAXF - 1, FL_MIDH = FL_TH * 2 + FL_MAXF - 1;   // worst case down=2
+constexpr int FL_INW = FL_MIDW + FL_MAXF, FL_INH = FL_MIDH + FL_MAXF;                 // worst case up=1
+
+struct FlArgs {
+    const void* x; const void* b; const float* fu; const float* fd; void* y;
+    int n, c, in_h, in_w, out_h, out_w, fu_h, fu_w, fd_h, fd_w, up, down, padx0, pady0, flip;
+    float alpha, gain, clamp;
+    int tiles_x, tiles_y;
+};
+
+template <class T>
+__global__ void __launch_bounds__(256) filtered_lrelu_kernel(FlArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_fu = smem;                              // [fu_h*fu_w] flipped
+    float* s_fd = s_fu + FL_MAXF * FL_MAXF;          // [fd_h*fd_w] flipped
+    float* s_in = s_fd + FL_MAXF * FL_MAXF;
+    const int tile_x = blockIdx.x % p.tiles_x, tile_y = (blockIdx.x / p.tiles_x) % p.tiles_y;
+    const int plane = blockIdx.x / (p.tiles_x * p.tiles_y);
+    const int ch = plane % p.c;
+    const int up = p.up, down = p.down;
+    // intermediate region needed by this output tile
+    const int mid_x0 = tile_x * FL_TW * down, mid_y0 = tile_y * FL_TH * down;
+    const int tw = min(FL_TW, p.out_w - tile_x * FL_TW), th = min(FL_TH, p.out_h - tile_y * FL_TH);
+    const int mid_w = (tw - 1) * down + p.fd_w, mid_h = (th - 1) * down + p.fd_h;
+    // input region needed by that intermediate region (same index path as upfirdn2d)
+    const int in_x0 = mg_floor_div(mid_x0 + up - 1 - p.padx0, up), in_y0 = mg_floor_div(mid_y0 + up - 1 - p.pady0, up);
+    const int in_x1 = mg_floor_div(mid_x0 + mid_w - 1 + up - 1 - p.padx0 + p.fu_w - 1, up);
+    const int in_y1 = mg_floor_div(mid_y0 + mid_h - 1 + up - 1 - p.pady0 + p.fu_h - 1, up);
+    const int in_w = in_x1 - in_x0 + 1, in_h = in_y1 - in_y0 + 1;
+    float* s_mid = s_in + in_w * in_h;
+
+    for (int i = threadIdx.x; i < p.fu_h * p.fu_w; i += 256) {
+        int ky = i / p.fu_w, kx = i - ky * p.fu_w;
+        s_fu[i] = p.fu[(p.flip ? ky : p.fu_h - 1 - ky) * p.fu_w + (p.flip ? kx : p.fu_w - 1 - kx)];
+    }
+    for (int i = threadIdx.x; i < p.fd_h * p.fd_w; i += 256) {
+        int ky = i / p.fd_w, kx = i - ky * p.fd_w;
+        s_fd[i] = p.fd[(p.flip ? ky : p.fd_h - 1 - ky) * p.fd_w + (p.flip ? kx : p.fd_w - 1 - kx)];
+    }
+    const float bias = p.b ? (float)to_acc<T>(((const T*)p.b)[ch]) : 0.f;
+    const T* xp = (const T*)p.x + (size_t)plane * p.in_h * p.in_w;
+    for (int i = threadIdx.x; i < in_w * in_h; i += 256) {
+        int ry = i / in_w, rx = i - ry * in_w, ix = in_x0 + rx, iy = in_y0 + ry;
+        float v = 0.f;
+        if (ix >= 0 && iy >= 0 && ix < p.in_w && iy < p.in_h) v = (float)to_acc<T>(xp[(size_t)iy * p.in_w + ix]) + bias;
+        s_in[i] = v;
+    }
+    __syncthreads();
+    const float up_gain = (float)(up * up);
+    for (int i = threadIdx.x; i < mid_w * mid_h; i += 256) {
+        int my = i / mid_w, mx = i - my * mid_w;
+        int midx = mid_x0 + mx + up - 1 - p.padx0, midy = mid_y0 + my + up - 1 - p.pady0;
+        int ix = mg_floor_div(midx, up), iy = mg_floor_div(midy, up);
+        int fx0 = (ix + 1) * up - midx - 1, fy0 = (iy + 1) * up - midy - 1;
+        float v = 0.f;
+        for (int ky = fy0, ry = iy - in_y0; ky < p.fu_h; ky += up, ry++)
+            for (int kx = fx0, rx = ix - in_x0; kx < p.fu_w; kx += up, rx++)
+                v += s_in[ry * in_w + rx] * s_fu[ky * p.fu_w + kx];
+        v *= up_gain;
+        // the composition rounds the up-sampled tensor to T, then bias_act (bias already added) rounds again
+        v = (float)to_acc<T>(from_acc<T>(v));
+        v = (v > 0.f ? v : v * p.alpha) * p.gain;
+        if (p.clamp >= 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+        s_mid[i] = (float)to_acc<T>(from_acc<T>(v));
+    }
+    __syncthreads();
+    T* yp = (T*)p.y + (size_t)plane * p.out_h * p.out_w;
+    for (int i = threadIdx.x; i < tw * th; i += 256) {
+        int oy = i / tw, ox = i - oy * tw;
+        float v = 0.f;
+        for (int ky = 0; ky < p.fd_h; ky++)
+            for (int kx = 0; kx < p.fd_w; kx++)
+                v += s_mid[(oy * down + ky) * mid_w + (ox * down + kx)] * s_fd[ky * p.fd_w + kx];
+        yp[(size_t)(tile_y * FL_TH + oy) * p.out_w + (tile_x * FL_TW + ox)] = from_acc<T>(v);
+    }
+}
+
+} // namespace
+
+extern "C" int mg_fma_bias_act(const void* x, const float* d, const float* noise, const void* b, void* y, int dtype,
+                               int act, float alpha, float gain, float clamp, float noise_gain, int32_t n, int32_t c,
+                               int32_t hw, void* stream)
+{
+    MG_REQUIRE(x && y, "x must reside on the device");
+    MG_REQUIRE(dtype == MG_F32 || dtype == MG_F16 || dtype == MG_BF16, "fma_bias_act: unsupported dtype %d", dtype);
+    MG_REQUIRE(n >= 0 && c >= 1 && hw >= 1, "fma_bias_act: bad shape");
+    int64_t total = (int64_t)n * c * hw;
+    MG_REQUIRE(total <= INT32_MAX, "x is too large");
+    if (total == 0) return MG_OK;
+    int es = mg_dtype_size(dtype), vec = 16 / es;
+    bool wide = (hw % vec == 0) && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    MgLaunchScope scope(MG_K_FMA_BIAS_ACT, s, 2.0 * total * es);
+    int rc = MG_OK;
+    MG_DISPATCH_DTYPE(dtype, {
+        if (sizeof(T) == 8) break;
+        FbArgs<T> p;
+        p.x = (const T*)x; p.d = d; p.noise = noise; p.b = (const T*)b; p.y = (T*)y; p.y2 = nullptr;
+        p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_gain = noise_gain;
+        p.c = (uint32_t)c; p.hw = (uint32_t)hw; p.total_vec = (uint32_t)total; p.c_div = make_fastdiv((uint32_t)c);
+        rc = dispatch_fb<T>(p, act, false, wide, s);
+    });
+    if (rc) return rc;
+    return mg_check_launch(MG_K_FMA_BIAS_ACT, "fma_bias_act");
+}
+
+extern "C" int mg_fma_bias_act_bwd(const void* dy, const void* yref, const float* d, void* dx, void* dpre, int dtype,
+                                   int act, float alpha, float gain, float clamp, int32_t n, int32_t c, int32_t hw,
+                                   void* stream)
+{
+    MG_REQUIRE(dy && yref && dx, "dy must reside on the device");
+    MG_REQUIRE(dtype == MG_F32 || dtype == MG_F16 || dtype == MG_BF16, "fma_bias_act: unsupported dtype %d", dtype);
+    MG_REQUIRE(n >= 0 && c >= 1 && hw >= 1, "fma_bias_act: bad shape");
+    int64_t total = (int64_t)n * c * hw;
+    MG_REQUIRE(total <= INT32_MAX, "x is too large");
+    if (total == 0) return MG_OK;
+    int es = mg_dtype_size(dtype), vec = 16 / es;
+    bool wide = (hw % vec == 0) && ((((uintptr_t)dy | (uintptr_t)yref | (uintptr_t)dx | (uintptr_t)dpre) & 15) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    MgLaunchScope scope(MG_K_FMA_BIAS_ACT, s, (3.0 + (dpre != nullptr)) * total * es);
+    int rc = MG_OK;
+    MG_DISPATCH_DTYPE(dtype, {
+        if (sizeof(T) == 8) break;
+        FbArgs<T> p;
+        p.x = (const T*)dy; p.d = d; p.noise = nullptr; p.b = (const T*)yref; p.y = (T*)dx; p.y2 = (T*)dpre;
+        p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_gain = 0.f;
+        p.c = (uint32_t)c; p.hw = (uint32_t)hw; p.total_vec = (uint32_t)total; p.c_div = make_fastdiv((uint32_t)c);
+        rc = dispatch_fb<T>(p, act, true, wide, s);
+    });
+    if (rc) return rc;
+    return mg_check_launch(MG_K_FMA_BIAS_ACT, "fma_bias_act_bwd");
+}
+
+extern "C" int mg_filtered_lrelu(const void* x, const void* b, const float* fu, const float* fd, void* y, int dtype,
+                                 int32_t n, int32_t c, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                                 int32_t fu_h, int32_t fu_w, int32_t fd_h, int32_t fd_w, int up, int down, int padx0,
+                                 int pady0, float alpha, float gain, float clamp, int flip, void* stream)
+{
+    MG_REQUIRE(x && fu && fd && y, "x must reside on the device");
+    MG_REQUIRE(dtype == MG_F32 || dtype == MG_F16 || dtype == MG_BF16, "filtered_lrelu: unsupported dtype %d", dtype);
+    MG_REQUIRE((up == 1 || up == 2) && (down == 1 || down == 2), "filtered_lrelu: up and down must be 1 or 2");
+    MG_REQUIRE(fu_h >= 1 && fu_w >= 1 && fd_h >= 1 && fd_w >= 1 && fu_h <= FL_MAXF && fu_w <= FL_MAXF &&
+               fd_h <= FL_MAXF && fd_w <= FL_MAXF, "filtered_lrelu: filters must be 1..%d taps per axis", FL_MAXF);
+    MG_REQUIRE(n >= 0 && c >= 1 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, "output must be at least 1x1");
+    MG_REQUIRE((int64_t)n * c * in_h * in_w <= INT32_MAX && (int64_t)n * c * out_h * out_w <= INT32_MAX, "x is too large");
+    if (n == 0) return MG_OK;
+    FlArgs p;
+    p.x = x; p.b = b; p.fu = fu; p.fd = fd; p.y = y;
+    p.n = n; p.c = c; p.in_h = in_h; p.in_w = in_w; p.out_h = out_h; p.out_w = out_w;
+    p.fu_h = fu_h; p.fu_w = fu_w; p.fd_h = fd_h; p.fd_w = fd_w; p.up = up; p.down = down;
+    p.padx0 = padx0; p.pady0 = pady0; p.flip = flip ? 1 : 0; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    p.tiles_x = (out_w + FL_TW - 1) / FL_TW; p.tiles_y = (out_h + FL_TH - 1) / FL_TH;
+    // LDS: worst-case footprint of one tile
+    int mid_w = (FL_TW - 1) * down + fd_w, mid_h = (FL_TH - 1) * down + fd_h;
+    int iw = (mid_w + fu_w - 1) / up + 2, ih = (mid_h + fu_h - 1) / up + 2;
+    size_t lds = sizeof(float) * (2 * FL_MAXF * FL_MAXF + (size_t)iw * ih + (size_t)mid_w * mid_h);
+    MG_REQUIRE(lds <= 160 * 1024, "filtered_lrelu: tile does not fit LDS");
+    hipStream_t s = (hipStream_t)stream;
+    int es = mg_dtype_size(dtype);
+    MgLaunchScope scope(MG_K_FILTERED_LRELU, s, ((double)n * c * in_h * in_w + (double)n * c * out_h * out_w) * es);
+    int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * n * c;
+    MG_REQUIRE(blocks <= INT32_MAX, "x is too large");
+    MG_DISPATCH_DTYPE(dtype, {
+        if (sizeof(T) == 8) break;
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)filtered_lrelu_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((filtered_lrelu_kernel<T>), dim3((uint32_t)blocks), dim3(256), lds, s, p);
+    });
+    return mg_check_launch(MG_K_FILTERED_LRELU, "filtered_lrelu");
+}

@@ -1,0 +1,331 @@
+// upfirdn2d.hip -- pad -> zero-upsample -> 2-D FIR -> decimate, fused, for gfx950.
+// Replaces upfirdn2d_plugin.upfirdn2d (reference torch_utils/ops/upfirdn2d.cu:29-200,
+// upfirdn2d.cpp:16-94).
+//
+// Two kernels:
+//  * upfirdn2d_generic: any strides / filter / factors / dtype.  One lane per
+//    output element, lanes ordered along the fastest output stride.  Integer
+//    receptive field by mg_axis() -- the bit-exact index path.
+//  * upfirdn2d_tiled<...>: dense NCHW, small filters, up/down in {1,2}: one
+//    workgroup stages the input footprint of a PZ x TH x TW output tile into LDS
+//    (fp32, zero filled outside the image), then every lane produces an MY x MX
+//    register micro-tile with all filter taps held in registers.  The polyphase
+//    structure (which taps hit non-zero samples) is resolved at compile time from
+//    the tile phase PX/PY, so an up=2 output costs (FW/2)*(FH/2) MACs.
+#include "mg_common.h"
+
+namespace {
+
+struct UfParams {
+    const void* x; const float* f; void* y;
+    int upx, upy, downx, downy, padx0, pady0, flip; float gain;
+    int n, c, in_h, in_w, out_h, out_w, f_h, f_w;
+    int64_t xs_n, xs_c, xs_h, xs_w, ys_n, ys_c, ys_h, ys_w, fs_h, fs_w;
+};
+
+// Integer receptive field of one output coordinate along one axis
+// (reference upfirdn2d.cu:43-48 / 60-65).  Same arithmetic as oracle orc_axis().
+__device__ __forceinline__ void mg_axis(int o, int up, int down, int pad0, int fsize, int in_size, int flip,
+                                        int& in0, int& count, int& f0)
+{
+    int mid = o * down + up - 1 - pad0;
+    int i0 = min(max(mg_floor_div(mid, up), 0), in_size);
+    int i1 = min(max(mg_floor_div(mid + fsize, up), 0), in_size);
+    int ff = mid + fsize - (i0 + 1) * up;
+    if (flip) ff = fsize - 1 - ff;
+    in0 = i0; count = i1 - i0; f0 = ff;
+}
+
+__global__ void upfirdn2d_index_table_kernel(int32_t* table, int out_size, int in_size, int up, int down, int pad0,
+                                             int fsize, int flip)
+{
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= out_size) return;
+    int a, b, c;
+    mg_axis(o, up, down, pad0, fsize, in_size, flip, a, b, c);
+    table[3 * o] = a; table[3 * o + 1] = b; table[3 * o + 2] = c;
+}
+
+// ---------------------------------------------------------------------------
+// Generic kernel.  CL = channel is the fastest output dimension.
+template <class T, bool CL>
+__global__ void __launch_bounds__(256) upfirdn2d_generic(UfParams p, uint32_t total)
+{
+    typedef typename Acc<T>::type acc_t;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        int ox, oy, c, n;
+        uint32_t r = idx;
+        if (CL) { c = r % p.c; r /= p.c; ox = r % p.out_w; r /= p.out_w; oy = r % p.out_h; n = r / p.out_h; }
+        else    { ox = r % p.out_w; r /= p.out_w; oy = r % p.out_h; r /= p.out_h; c = r % p.c; n = r / p.c; }
+        int ix0, w, fx0, iy0, h, fy0;
+        mg_axis(ox, p.upx, p.downx, p.padx0, p.f_w, p.in_w, p.flip, ix0, w, fx0);
+        mg_axis(oy, p.upy, p.downy, p.pady0, p.f_h, p.in_h, p.flip, iy0, h, fy0);
+        const int64_t fstep_x = (p.flip ? p.upx : -p.upx) * p.fs_w;
+        const int64_t fstep_y = (p.flip ? p.upy : -p.upy) * p.fs_h;
+        const T* xp = (const T*)p.x + n * p.xs_n + c * p.xs_c + iy0 * p.xs_h + ix0 * p.xs_w;
+        const float* fp = p.f + fy0 * p.fs_h + fx0 * p.fs_w;
+        acc_t v = 0;
+        for (int j = 0; j < h; j++) {
+            const T* xr = xp + j * p.xs_h;
+            const float* fr = fp + j * fstep_y;
+            for (int i = 0; i < w; i++)
+                v += to_acc<T>(xr[i * p.xs_w]) * (acc_t)fr[i * fstep_x];
+        }
+        v *= (acc_t)p.gain;
+        ((T*)p.y)[n * p.ys_n + c * p.ys_c + oy * p.ys_h + ox * p.ys_w] = from_acc<T>(v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Tiled kernel, dense NCHW.
+//   UPX/UPY, DNX/DNY  resampling factors (1 or 2)
+//   FW/FH             template filter footprint; shorter filters are zero extended
+//                     at the far end of the flipped filter (harmless, reference
+//                     upfirdn2d.cu:118-130 does the same)
+//   PX/PY             phase of the tile origin: (tile_out0*DN + UP-1-pad0) mod UP
+//   TXT x TYT lanes per plane, MX x MY outputs per lane, PZ planes per workgroup
+template <int UPX, int UPY, int DNX, int DNY, int FW, int FH, int PX, int PY, int TXT, int TYT, int MX, int MY>
+struct TileGeom {
+    static constexpr int PZ = 256 / (TXT * TYT);
+    static constexpr int TW = TXT * MX, TH = TYT * MY;                        // output tile
+    static constexpr int TIW = (PX + (TW - 1) * DNX + FW - 1) / UPX + 1;     // input footprint
+    static constexpr int TIH = (PY + (TH - 1) * DNY + FH - 1) / UPY + 1;
+    static constexpr int LDW = TIW | 1;                                       // odd row pitch: no bank conflicts
+    static constexpr int RX = (PX + (MX - 1) * DNX + FW - 1) / UPX + 1;      // per-lane register window
+    static constexpr int RY = (PY + (MY - 1) * DNY + FH - 1) / UPY + 1;
+    static constexpr int LANE_DX = MX * DNX / UPX, LANE_DY = MY * DNY / UPY;  // window origin step per lane
+    static_assert((MX * DNX) % UPX == 0 && (MY * DNY) % UPY == 0, "micro tile must span whole input samples");
+    static_assert((TW * DNX) % UPX == 0 && (TH * DNY) % UPY == 0, "tile phase must repeat");
+};
+
+template <class T, int UPX, int UPY, int DNX, int DNY, int FW, int FH, int PX, int PY, int TXT, int TYT, int MX, int MY>
+__global__ void __launch_bounds__(256) upfirdn2d_tiled(UfParams p, int tiles_x, int tiles_y)
+{
+    typedef TileGeom<UPX, UPY, DNX, DNY, FW, FH, PX, PY, TXT, TYT, MX, MY> G;
+    __shared__ float sx[G::PZ][G::TIH][G::LDW];
+
+    // taps of the flipped, zero-extended filter; uniform -> scalar registers
+    float ft[FH][FW];
+    #pragma unroll
+    for (int ky = 0; ky < FH; ky++)
+        #pragma unroll
+        for (int kx = 0; kx < FW; kx++) {
+            float v = 0.f;
+            if (kx < p.f_w && ky < p.f_h) {
+                int sx_ = p.flip ? kx : p.f_w - 1 - kx;
+                int sy_ = p.flip ? ky : p.f_h - 1 - ky;
+                v = p.f[sy_ * p.fs_h + sx_ * p.fs_w];
+            }
+            ft[ky][kx] = v;
+        }
+
+    const int planes = p.n * p.c;
+    const int tile_x = blockIdx.x % tiles_x;
+    const int tile_y = (blockIdx.x / tiles_x) % tiles_y;
+    const int plane0 = (blockIdx.x / (tiles_x * tiles_y)) * G::PZ;
+    const int out_x0 = tile_x * G::TW, out_y0 = tile_y * G::TH;
+    // first input sample of the tile footprint (may be negative / beyond the image)
+    const int in_x0 = mg_floor_div(out_x0 * DNX + UPX - 1 - p.padx0, UPX);
+    const int in_y0 = mg_floor_div(out_y0 * DNY + UPY - 1 - p.pady0, UPY);
+
+    // stage the footprint, zero filled, as fp32
+    for (int i = threadIdx.x; i < G::PZ * G::TIH * G::TIW; i += 256) {
+        int rx = i % G::TIW, t = i / G::TIW, ry = t % G::TIH, pz = t / G::TIH;
+        int ix = in_x0 + rx, iy = in_y0 + ry, plane = plane0 + pz;
+        float v = 0.f;
+        if (ix >= 0 && iy >= 0 && ix < p.in_w && iy < p.in_h && plane < planes)
+            v = (float)to_acc<T>(((const T*)p.x)[(int64_t)plane * p.in_h * p.in_w + (int64_t)iy * p.in_w + ix]);
+        sx[pz][ry][rx] = v;
+    }
+    __syncthreads();
+
+    const int tx = threadIdx.x % TXT, ty = (threadIdx.x / TXT) % TYT, pz = threadIdx.x / (TXT * TYT);
+    const int plane = plane0 + pz;
+
+    float acc[MY][MX];
+    #pragma unroll
+    for (int j = 0; j < MY; j++)
+        #pragma unroll
+        for (int i = 0; i < MX; i++) acc[j][i] = 0.f;
+
+    // walk the register window row by row; every (row, output row) pair that meets a
+    // non-zero polyphase tap is a compile-time decision
+    #pragma unroll
+    for (int ry = 0; ry < G::RY; ry++) {
+        float row[G::RX];
+        #pragma unroll
+        for (int rx = 0; rx < G::RX; rx++) row[rx] = sx[pz][ty * G::LANE_DY + ry][tx * G::LANE_DX + rx];
+        #pragma unroll
+        for (int j = 0; j < MY; j++) {
+            // up-sampled position of output j's first tap relative to the lane window
+            const int my = PY + j * DNY;                 // = phase + offset, in up-sampled samples
+            const int iy_first = my / UPY;               // first input row touched
+            const int fy_first = (iy_first + 1) * UPY - my - 1;   // its tap in the flipped filter
+            const int ky = fy_first + (ry - iy_first) * UPY;      // tap that row `ry` meets
+            if (ry < iy_first || ky >= FH) continue;
+            #pragma unroll
+            for (int i = 0; i < MX; i++) {
+                const int mx = PX + i * DNX;
+                const int ix_first = mx / UPX;
+                const int fx_first = (ix_first + 1) * UPX - mx - 1;
+                #pragma unroll
+                for (int kx = fx_first, rx = ix_first; kx < FW; kx += UPX, rx++)
+                    acc[j][i] += row[rx] * ft[ky][kx];
+            }
+        }
+    }
+
+    if (plane >= planes) return;
+    T* yp = (T*)p.y + (int64_t)plane * p.out_h * p.out_w;
+    #pragma unroll
+    for (int j = 0; j < MY; j++) {
+        int oy = out_y0 + ty * MY + j;
+        if (oy >= p.out_h) continue;
+        #pragma unroll
+        for (int i = 0; i < MX; i++) {
+            int ox = out_x0 + tx * MX + i;
+            if (ox < p.out_w) yp[(int64_t)oy * p.out_w + ox] = from_acc<T>(acc[j][i] * p.gain);
+        }
+    }
+}
+
+template <class T, int UPX, int UPY, int DNX, int DNY, int FW, int FH, int PX, int PY, int TXT, int TYT, int MX, int MY>
+void launch_tiled_geom(const UfParams& p, hipStream_t s)
+{
+    typedef TileGeom<UPX, UPY, DNX, DNY, FW, FH, PX, PY, TXT, TYT, MX, MY> G;
+    int tiles_x = (p.out_w + G::TW - 1) / G::TW, tiles_y = (p.out_h + G::TH - 1) / G::TH;
+    int planes = p.n * p.c;
+    int64_t blocks = (int64_t)tiles_x * tiles_y * ((planes + G::PZ - 1) / G::PZ);
+    hipLaunchKernelGGL((upfirdn2d_tiled<T, UPX, UPY, DNX, DNY, FW, FH, PX, PY, TXT, TYT, MX, MY>), dim3((uint32_t)blocks),
+                       dim3(256), 0, s, p, tiles_x, tiles_y);
+}
+
+// choose lanes-per-plane from the output size: big planes get 32x8 lanes (128x32 outputs
+// at MX=MY=4), small planes pack several per workgroup
+template <class T, int UPX, int UPY, int DNX, int DNY, int FW, int FH, int PX, int PY, int MX, int MY>
+void launch_tiled_phase(const UfParams& p, hipStream_t s)
+{
+    if (p.out_w > 16 * MX)      launch_tiled_geom<T, UPX, UPY, DNX, DNY, FW, FH, PX, PY, 32, 8, MX, MY>(p, s);
+    else if (p.out_w > 8 * MX)  launch_tiled_geom<T, UPX, UPY, DNX, DNY, FW, FH, PX, PY, 16, 16, MX, MY>(p, s);
+    else if (p.out_w > 4 * MX)  launch_tiled_geom<T, UPX, UPY, DNX, DNY, FW, FH, PX, PY, 8, 8, MX, MY>(p, s);
+    else                        launch_tiled_geom<T, UPX, UPY, DNX, DNY, FW, FH, PX, PY, 4, 4, MX, MY>(p, s);
+}
+
+template <class T, int UPX, int UPY, int DNX, int DNY, int FW, int FH, int MX, int MY>
+void launch_tiled(const UfParams& p, hipStream_t s)
+{
+    // tile origins are multiples of TW*DN (a multiple of UP), so the phase is the same for every tile
+    int px = ((UPX - 1 - p.padx0) % UPX + UPX) % UPX;
+    int py = ((UPY - 1 - p.pady0) % UPY + UPY) % UPY;
+    if (UPX == 1 && UPY == 1) { launch_tiled_phase<T, UPX, UPY, DNX, DNY, FW, FH, 0, 0, MX, MY>(p, s); return; }
+    if (UPX == 2 && UPY == 2) {
+        if (px == 0 && py == 0) launch_tiled_phase<T, UPX, UPY, DNX, DNY, FW, FH, 0, 0, MX, MY>(p, s);
+        if (px == 1 && py == 0) launch_tiled_phase<T, UPX, UPY, DNX, DNY, FW, FH, (UPX > 1), 0, MX, MY>(p, s);
+        if (px == 0 && py == 1) launch_tiled_phase<T, UPX, UPY, DNX, DNY, FW, FH, 0, (UPY > 1), MX, MY>(p, s);
+        if (px == 1 && py == 1) launch_tiled_phase<T, UPX, UPY, DNX, DNY, FW, FH, (UPX > 1), (UPY > 1), MX, MY>(p, s);
+        return;
+    }
+    if (UPX == 2) {
+        if (px == 0) launch_tiled_phase<T, UPX, UPY, DNX, DNY, FW, FH, 0, 0, MX, MY>(p, s);
+        else         launch_tiled_phase<T, UPX, UPY, DNX, DNY, FW, FH, (UPX > 1), 0, MX, MY>(p, s);
+        return;
+    }
+    if (py == 0) launch_tiled_phase<T, UPX, UPY, DNX, DNY, FW, FH, 0, 0, MX, MY>(p, s);
+    else         launch_tiled_phase<T, UPX, UPY, DNX, DNY, FW, FH, 0, (UPY > 1), MX, MY>(p, s);
+}
+
+// Returns true when a tiled specialisation took the call.
+template <class T>
+bool try_tiled(const UfParams& p, hipStream_t s)
+{
+    const bool dense = p.xs_w == 1 && p.xs_h == p.in_w && p.xs_c == (int64_t)p.in_h * p.in_w &&
+                       p.xs_n == (int64_t)p.c * p.in_h * p.in_w && p.ys_w == 1 && p.ys_h == p.out_w &&
+                       p.ys_c == (int64_t)p.out_h * p.out_w && p.ys_n == (int64_t)p.c * p.out_h * p.out_w;
+    if (!dense) return false;
+    const int ux = p.upx, uy = p.upy, dx = p.downx, dy = p.downy, fw = p.f_w, fh = p.f_h;
+#define UF_CASE(UX, UY, DX, DY, FW_, FH_, MX_, MY_)                                                       \
+    if (ux == UX && uy == UY && dx == DX && dy == DY && fw <= FW_ && fh <= FH_) {                         \
+        launch_tiled<T, UX, UY, DX, DY, FW_, FH_, MX_, MY_>(p, s); return true; }
+    // 2-D filters of the networks ([1,3,3,1] outer product)
+    UF_CASE(1, 1, 1, 1, 4, 4, 4, 4)
+    UF_CASE(2, 2, 1, 1, 4, 4, 4, 4)
+    UF_CASE(1, 1, 2, 2, 4, 4, 2, 2)
+    // separable passes of ADA (12-tap sym6), and their gradients
+    UF_CASE(1, 1, 1, 1, 12, 1, 4, 4)
+    UF_CASE(1, 1, 1, 1, 1, 12, 4, 4)
+    UF_CASE(2, 1, 1, 1, 12, 1, 4, 4)
+    UF_CASE(1, 2, 1, 1, 1, 12, 4, 4)
+    UF_CASE(1, 1, 2, 1, 12, 1, 4, 4)
+    UF_CASE(1, 1, 1, 2, 1, 12, 4, 4)
+#undef UF_CASE
+    return false;
+}
+
+} // namespace
+
+extern "C" int mg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                            const int32_t x_size[4], const int64_t x_stride[4],
+                            const int32_t f_size[2], const int64_t f_stride[2],
+                            const int32_t y_size[4], const int64_t y_stride[4],
+                            int upx, int upy, int downx, int downy, int padx0, int pady0, int flip, float gain,
+                            void* stream)
+{
+    MG_REQUIRE(x && f && y, "x must reside on the device");
+    MG_REQUIRE(f_size[0] >= 1 && f_size[1] >= 1, "f must be at least 1x1");                 // upfirdn2d.cpp:26
+    MG_REQUIRE(upx >= 1 && upy >= 1, "upsampling factor must be at least 1");               // upfirdn2d.cpp:27
+    MG_REQUIRE(downx >= 1 && downy >= 1, "downsampling factor must be at least 1");         // upfirdn2d.cpp:28
+    MG_REQUIRE(y_size[2] >= 1 && y_size[3] >= 1, "output must be at least 1x1");            // upfirdn2d.cpp:34
+    MG_REQUIRE(x_size[0] == y_size[0] && x_size[1] == y_size[1], "x and y must agree in batch and channels");
+    int64_t xn = (int64_t)x_size[0] * x_size[1] * x_size[2] * x_size[3];
+    int64_t yn = (int64_t)y_size[0] * y_size[1] * y_size[2] * y_size[3];
+    MG_REQUIRE(xn <= INT32_MAX, "x is too large");                                           // upfirdn2d.cpp:22
+    MG_REQUIRE(yn <= INT32_MAX, "output is too large");                                      // upfirdn2d.cpp:36
+    int es = mg_dtype_size(dtype);
+    MG_REQUIRE(es > 0, "unsupported dtype %d", dtype);
+    if (yn == 0) return MG_OK;
+
+    UfParams p;
+    p.x = x; p.f = f; p.y = y;
+    p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0;
+    p.flip = flip ? 1 : 0; p.gain = gain;
+    p.n = x_size[0]; p.c = x_size[1]; p.in_h = x_size[2]; p.in_w = x_size[3];
+    p.out_h = y_size[2]; p.out_w = y_size[3]; p.f_h = f_size[0]; p.f_w = f_size[1];
+    p.xs_n = x_stride[0]; p.xs_c = x_stride[1]; p.xs_h = x_stride[2]; p.xs_w = x_stride[3];
+    p.ys_n = y_stride[0]; p.ys_c = y_stride[1]; p.ys_h = y_stride[2]; p.ys_w = y_stride[3];
+    p.fs_h = f_stride[0]; p.fs_w = f_stride[1];
+    hipStream_t s = (hipStream_t)stream;
+
+    bool tiled = false;
+    {
+        MgLaunchScope scope(MG_K_UPFIRDN2D_TILED, s, (double)(xn + yn) * es);
+        switch (dtype) {
+        case MG_F32:  tiled = try_tiled<float>(p, s); break;
+        case MG_F16:  tiled = try_tiled<mg_half>(p, s); break;
+        case MG_BF16: tiled = try_tiled<mg_bf16>(p, s); break;
+        default: break;
+        }
+        if (!tiled) scope.kid = -1;
+    }
+    if (tiled) return mg_check_launch(MG_K_UPFIRDN2D_TILED, "upfirdn2d");
+
+    MgLaunchScope scope(MG_K_UPFIRDN2D_GENERIC, s, (double)(xn + yn) * es);
+    uint32_t total = (uint32_t)yn;
+    uint32_t blocks = (total + 255u) / 256u;
+    if (blocks > 256u * 16u) blocks = 256u * 16u;
+    const bool cl = (p.ys_c == 1 && p.c > 1);
+    MG_DISPATCH_DTYPE(dtype, {
+        if (cl) hipLaunchKernelGGL((upfirdn2d_generic<T, true>), dim3(blocks), dim3(256), 0, s, p, total);
+        else    hipLaunchKernelGGL((upfirdn2d_generic<T, false>), dim3(blocks), dim3(256), 0, s, p, total);
+    });
+    return mg_check_launch(MG_K_UPFIRDN2D_GENERIC, "upfirdn2d");
+}
+
+extern "C" int mg_upfirdn2d_index_table(int32_t* table, int out_size, int in_size, int up, int down, int pad0,
+                                        int filter_size, int flip, void* stream)
+{
+    MG_REQUIRE(table && out_size >= 1, "table must hold out_size*3 ints");
+    MG_REQUIRE(up >= 1 && down >= 1 && filter_size >= 1, "up, down and filter_size must be at least 1");
+    hipLaunchKernelGGL(upfirdn2d_index_table_kernel, dim3((out_size + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       table, out_size, in_size, up, down, pad0, filter_size, flip ? 1 : 0);
+    return mg_check_launch(-1, "upfirdn2d_index_table");
+}

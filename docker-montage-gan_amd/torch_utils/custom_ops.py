@@ -1,0 +1,147 @@
+"""Plugin loader with the reference's interface (montage_gan/torch_utils/custom_ops.py:23,49).
+
+``get_plugin(module_name, sources, **build_kwargs)`` returns an object exposing the same
+functions as the reference's pybind modules:
+
+    upfirdn2d_plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
+    bias_act_plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)
+
+Behind them is libmontage_hip.so (C ABI in include/montage_hip.h), compiled ahead of time
+for gfx950 instead of JIT-built per process, so there is no FileBaton / md5 build cache to
+keep.  ``sources`` and ``build_kwargs`` are accepted for call compatibility and ignored.
+A load failure RAISES; callers never get a silent slow path.
+"""
+import torch
+
+from . import native
+
+verbosity = 'brief'  # 'none' | 'brief' | 'full'   (custom_ops.py:23)
+
+_cached_plugins = dict()
+_null = None
+
+
+def _is_null(t):
+    return t is None or t.numel() == 0
+
+
+def _suggest_memory_format(x):
+    # at::Tensor::suggest_memory_format() for rank 4 (upfirdn2d.cpp:35)
+    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+        return torch.channels_last
+    return torch.contiguous_format
+
+
+def _has_same_layout(a, b):
+    # bias_act.cpp:16-28
+    if a.dim() != b.dim():
+        return False
+    for i in range(a.dim()):
+        if a.size(i) != b.size(i):
+            return False
+        if a.size(i) >= 2 and a.stride(i) != b.stride(i):
+            return False
+    return True
+
+
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+class _Upfirdn2dPlugin:
+    """Stands where ``upfirdn2d_plugin`` (upfirdn2d.cpp:98-101) stood."""
+
+    @staticmethod
+    def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
+        _require(x.is_cuda, 'x must reside on CUDA device')                                    # upfirdn2d.cpp:19
+        _require(f.device == x.device, 'f must reside on the same device as x')                # :20
+        _require(f.dtype == torch.float32, 'f must be float32')                                # :21
+        _require(x.numel() <= 2 ** 31 - 1, 'x is too large')                                   # :22
+        _require(f.numel() <= 2 ** 31 - 1, 'f is too large')                                   # :23
+        _require(x.dim() == 4, 'x must be rank 4')                                             # :24
+        _require(f.dim() == 2, 'f must be rank 2')                                             # :25
+        _require(f.size(0) >= 1 and f.size(1) >= 1, 'f must be at least 1x1')                  # :26
+        _require(upx >= 1 and upy >= 1, 'upsampling factor must be at least 1')                # :27
+        _require(downx >= 1 and downy >= 1, 'downsampling factor must be at least 1')          # :28
+        n, c, ih, iw = x.shape
+
+        def cdiv(a, b):  # C integer division truncates toward zero (upfirdn2d.cpp:32-33)
+            return int(a / b) if a * b < 0 else a // b
+
+        ow = cdiv(iw * upx + padx0 + padx1 - f.size(1) + downx, downx)
+        oh = cdiv(ih * upy + pady0 + pady1 - f.size(0) + downy, downy)
+        _require(ow >= 1 and oh >= 1, 'output must be at least 1x1')                           # :34
+        y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device, memory_format=_suggest_memory_format(x))
+        _require(y.numel() <= 2 ** 31 - 1, 'output is too large')                              # :36
+        with torch.cuda.device(x.device):
+            rc = native.lib().mg_upfirdn2d(
+                native.ptr(x), native.ptr(f), native.ptr(y), native.dtype_code(x.dtype),
+                native.I32x4(n, c, ih, iw), native.I64x4(*x.stride()),
+                native.I32x2(f.size(0), f.size(1)), native.I64x2(*f.stride()),
+                native.I32x4(n, c, oh, ow), native.I64x4(*y.stride()),
+                int(upx), int(upy), int(downx), int(downy), int(padx0), int(pady0), 1 if flip else 0, float(gain),
+                native.stream_ptr(x.device))
+        native.check(rc)
+        return y
+
+
+class _BiasActPlugin:
+    """Stands where ``bias_act_plugin`` (bias_act.cpp:94-97) stood."""
+
+    @staticmethod
+    def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
+        _require(x.is_cuda, 'x must reside on CUDA device')                                    # bias_act.cpp:35
+        _require(_is_null(b) or (b.dtype == x.dtype and b.device == x.device),
+                 'b must have the same dtype and device as x')                                 # :36
+        for t, name in ((xref, 'xref'), (yref, 'yref')):
+            _require(_is_null(t) or (t.shape == x.shape and t.dtype == x.dtype and t.device == x.device),
+                     f'{name} must have the same shape, dtype, and device as x')               # :37-38
+        _require(_is_null(dy) or (dy.shape == x.shape and dy.dtype == x.dtype and dy.device == x.device),
+                 'dy must have the same dtype and device as x')                                # :39
+        _require(x.numel() <= 2 ** 31 - 1, 'x is too large')                                   # :40
+        _require(b is None or b.dim() == 1, 'b must have rank 1')                              # :41
+        _require(_is_null(b) or (0 <= dim < x.dim()), 'dim is out of bounds')                  # :42
+        _require(_is_null(b) or b.numel() == x.size(dim), 'b has wrong number of elements')    # :43
+        _require(grad >= 0, 'grad must be non-negative')                                       # :44
+        _require(x.is_non_overlapping_and_dense(), 'x must be non-overlapping and dense')      # :47
+        _require(_is_null(b) or b.is_contiguous(), 'b must be contiguous')                     # :48
+        for t, name in ((xref, 'xref'), (yref, 'yref'), (dy, 'dy')):
+            _require(_is_null(t) or _has_same_layout(t, x), f'{name} must have the same layout as x')  # :49-51
+        y = torch.empty_like(x)
+        _require(_has_same_layout(y, x), 'y must have the same layout as x')                   # :56
+        has_b = not _is_null(b)
+        with torch.cuda.device(x.device):
+            rc = native.lib().mg_bias_act(
+                native.ptr(x), native.ptr(b if has_b else None),
+                native.ptr(None if _is_null(xref) else xref), native.ptr(None if _is_null(yref) else yref),
+                native.ptr(None if _is_null(dy) else dy), native.ptr(y), native.dtype_code(x.dtype),
+                int(grad), int(act), float(alpha), float(gain), float(clamp),
+                x.numel(), b.numel() if has_b else 0, x.stride(dim) if has_b else 1,
+                native.stream_ptr(x.device))
+        native.check(rc)
+        return y
+
+
+_PLUGINS = {'upfirdn2d_plugin': _Upfirdn2dPlugin, 'bias_act_plugin': _BiasActPlugin}
+
+
+def get_plugin(module_name, sources=None, **build_kwargs):
+    assert verbosity in ['none', 'brief', 'full']
+    if module_name in _cached_plugins:
+        return _cached_plugins[module_name]
+    if module_name not in _PLUGINS:
+        raise RuntimeError(f'unknown plugin "{module_name}"; libmontage_hip.so provides {sorted(_PLUGINS)}')
+    if verbosity != 'none':
+        print(f'Setting up PyTorch plugin "{module_name}"... ', end='', flush=True)
+    try:
+        native.lib()          # raises when the shared library is missing
+    except Exception:
+        if verbosity != 'none':
+            print('Failed!')
+        raise
+    if verbosity != 'none':
+        print('Done.')
+    plugin = _PLUGINS[module_name]
+    _cached_plugins[module_name] = plugin
+    return plugin

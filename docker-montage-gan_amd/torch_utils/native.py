@@ -1,0 +1,135 @@
+"""ctypes binding of libmontage_hip.so (C ABI: include/montage_hip.h).
+
+No CPU fallback lives here: if the shared library is missing or fails to load,
+``lib()`` raises, and so does every op that was handed a GPU tensor.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+# csrc/ sits next to torch_utils/ (both in this repo and when dropped into the reference's
+# montage_gan/ directory); MONTAGE_HIP_LIB overrides the location of the built library.
+CSRC = os.path.join(os.path.dirname(_HERE), 'csrc')
+LIB_PATH = os.environ.get('MONTAGE_HIP_LIB', os.path.join(CSRC, 'libmontage_hip.so'))
+
+MG_F32, MG_F16, MG_BF16, MG_F64 = 0, 1, 2, 3
+K_UPFIRDN2D_GENERIC, K_UPFIRDN2D_TILED, K_BIAS_ACT, K_FMA_BIAS_ACT = 0, 1, 2, 3
+K_ALPHA_COMPOSITE_FWD, K_ALPHA_COMPOSITE_BWD, K_TRANSLATE_FWD, K_TRANSLATE_BWD_INPUT = 4, 5, 6, 7
+K_TRANSLATE_BWD_SHIFT, K_FILTERED_LRELU = 8, 9
+KERNEL_NAMES = {0: 'upfirdn2d_generic', 1: 'upfirdn2d_tiled', 2: 'bias_act', 3: 'fma_bias_act', 4: 'alpha_composite_fwd',
+                5: 'alpha_composite_bwd', 6: 'translate_fwd', 7: 'translate_bwd_input', 8: 'translate_bwd_shift',
+                9: 'filtered_lrelu'}
+
+_lib = None
+_lock = threading.Lock()
+
+c_int, c_i32, c_i64, c_float, c_void_p = ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+I32x4, I64x4, I32x2, I64x2 = c_i32 * 4, c_i64 * 4, c_i32 * 2, c_i64 * 2
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into csrc/libmontage_hip.so (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.run(['make', '-C', CSRC, '-j', str(min(8, os.cpu_count() or 1))], check=True, stdout=out)
+    return LIB_PATH
+
+
+def _declare(L):
+    L.mg_abi_version.restype = c_int
+    L.mg_last_error.restype = ctypes.c_char_p
+    L.mg_launch_count.restype = ctypes.c_uint64
+    L.mg_launch_count.argtypes = [c_int]
+    L.mg_prof_enable.argtypes = [c_int]
+    L.mg_prof_collect.argtypes = [c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
+                                  ctypes.POINTER(ctypes.c_double)]
+    L.mg_upfirdn2d.argtypes = [c_void_p, c_void_p, c_void_p, c_int, I32x4, I64x4, I32x2, I64x2, I32x4, I64x4,
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]
+    L.mg_upfirdn2d_index_table.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    L.mg_bias_act.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                              c_float, c_float, c_float, c_i64, c_i32, c_i64, c_void_p]
+    L.mg_fma_bias_act.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
+                                  c_float, c_float, c_i32, c_i32, c_i32, c_void_p]
+    L.mg_fma_bias_act_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
+                                      c_float, c_i32, c_i32, c_i32, c_void_p]
+    L.mg_alpha_composite_fwd.argtypes = [c_void_p, c_void_p, c_int, c_i32, c_i32, c_i32, c_i32, c_void_p]
+    L.mg_alpha_composite_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_i32, c_i32, c_i32, c_i32, c_int, c_void_p]
+    L.mg_translate_sample_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_i32, c_i32, c_i32, c_i32, c_float, c_void_p]
+    L.mg_translate_sample_bwd_input.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_i32, c_i32, c_i32, c_i32, c_void_p]
+    L.mg_translate_sample_bwd_shift.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i32, c_i32, c_i32, c_i32,
+                                                c_float, c_void_p]
+    L.mg_filtered_lrelu.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_i32] * 10 + \
+                                   [c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p]
+    for name in ('mg_upfirdn2d', 'mg_upfirdn2d_index_table', 'mg_bias_act', 'mg_fma_bias_act', 'mg_fma_bias_act_bwd',
+                 'mg_alpha_composite_fwd', 'mg_alpha_composite_bwd', 'mg_translate_sample_fwd',
+                 'mg_translate_sample_bwd_input', 'mg_translate_sample_bwd_shift', 'mg_filtered_lrelu',
+                 'mg_prof_enable', 'mg_prof_collect', 'mg_prof_reset'):
+        getattr(L, name).restype = c_int
+
+
+def lib():
+    """The loaded library.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                        f'(or `make -C {CSRC}`).  There is no CPU fallback for GPU tensors.')
+                L = ctypes.CDLL(LIB_PATH)
+                _declare(L)
+                _lib = L
+    return _lib
+
+
+def check(rc):
+    """Turn a negative MG_E_* into the RuntimeError a TORCH_CHECK would have raised."""
+    if rc != 0:
+        raise RuntimeError(lib().mg_last_error().decode('utf-8', 'replace'))
+
+
+def launch_count(kernel_id):
+    return int(lib().mg_launch_count(kernel_id))
+
+
+def launch_counts():
+    return {name: launch_count(k) for k, name in KERNEL_NAMES.items()}
+
+
+def prof_enable(on=True):
+    lib().mg_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    lib().mg_prof_reset()
+
+
+def prof_collect():
+    """{kernel name: dict(launches, ms, bytes)} for kernels launched while profiling was on."""
+    out = {}
+    for k, name in KERNEL_NAMES.items():
+        n, ms, by = ctypes.c_uint64(0), ctypes.c_double(0), ctypes.c_double(0)
+        check(lib().mg_prof_collect(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)))
+        if n.value:
+            out[name] = dict(launches=int(n.value), ms=float(ms.value), bytes=float(by.value))
+    return out
+
+
+def dtype_code(torch_dtype):
+    import torch
+    table = {torch.float32: MG_F32, torch.float16: MG_F16, torch.bfloat16: MG_BF16, torch.float64: MG_F64}
+    if torch_dtype not in table:
+        raise RuntimeError(f'unsupported dtype {torch_dtype}')
+    return table[torch_dtype]
+
+
+def stream_ptr(device):
+    """Handle of torch's CURRENT stream on `device` (the contract of the reference plugins, upfirdn2d.cpp:92)."""
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)

@@ -1,0 +1,457 @@
+"""Parity tests proper: the hand-written HIP kernels (called through the C ABI, via the plugin
+API) against the CPU oracle and the reference's golden vectors.  Need a real MI355X.
+
+Tolerances: integer index path bit exact; float32 values within 1e-3 (BASELINE north star; most
+checks use 1e-4/1e-5); float16 within 4e-3, bfloat16 within 3e-2 relative to the magnitude of
+the result (their epsilons are 9.8e-4 and 7.8e-3)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, load_pkg
+from test_ops_ref_golden import run_bias_act_case, run_conv_case, run_upfirdn2d_case, T
+
+pytestmark = pytest.mark.gpu
+PKG = 'docker-montage-gan_amd'
+DEV = 'cuda:0'
+
+
+def op(name):
+    load_pkg()
+    return importlib.import_module(f'{PKG}.torch_utils.ops.{name}')
+
+
+def custom_ops():
+    load_pkg()
+    return importlib.import_module(f'{PKG}.torch_utils.custom_ops')
+
+
+@pytest.fixture(scope='module')
+def native():
+    n = load_pkg().native
+    n.lib()
+    return n
+
+
+def close_lowp(got, want, dtype, what=''):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    scale = max(1.0, float(np.abs(want).max()))
+    tol = {torch.float32: 1e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2, torch.float64: 1e-6}[dtype]
+    err = np.abs(got - want).max() / scale
+    assert err <= tol, f'{what}: max err {err:.3e} > {tol:.1e} ({dtype})'
+
+
+# --------------------------------------------------------------------------------------------
+# upfirdn2d
+
+def test_upfirdn2d_golden_fwd_bwd(native):
+    U = op('upfirdn2d')
+    cases, arr = load_golden('upfirdn2d')
+    before = native.launch_count(native.K_UPFIRDN2D_GENERIC) + native.launch_count(native.K_UPFIRDN2D_TILED)
+    for c in cases:
+        i = c['id']
+        y, dx = run_upfirdn2d_case(U, c, arr, device=DEV, impl='cuda')
+        assert list(y.shape) == c['out_shape'], c
+        if c['memfmt'] == 'channels_last':
+            assert y.is_contiguous(memory_format=torch.channels_last), c      # suggest_memory_format (upfirdn2d.cpp:35)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), arr[f'c{i}_y'], rtol=1e-4, atol=1e-5, err_msg=str(c))
+        np.testing.assert_allclose(dx.cpu().numpy(), arr[f'c{i}_dx'], rtol=1e-4, atol=1e-5, err_msg=str(c))
+    after = native.launch_count(native.K_UPFIRDN2D_GENERIC) + native.launch_count(native.K_UPFIRDN2D_TILED)
+    assert after - before >= 2 * len(cases), 'the native kernels did not run'
+
+
+def test_upfirdn2d_index_table_bit_exact(native, oracle):
+    """The integer index path computed ON THE DEVICE equals the oracle's, bit for bit."""
+    for up, down, fs, pad0, in_size, flip in [(1, 1, 4, 1, 257, 0), (2, 1, 4, 2, 128, 0), (1, 2, 4, 1, 256, 1),
+                                              (2, 1, 12, 6, 134, 0), (1, 2, 12, 5, 268, 1), (3, 2, 7, -3, 50, 0),
+                                              (4, 3, 5, 11, 17, 1), (1, 1, 1, 0, 9, 0), (2, 2, 4, -1, 33, 0)]:
+        out = oracle.out_size(in_size, up, down, pad0, pad0 + 1, fs)
+        tab = torch.empty([out, 3], dtype=torch.int32, device=DEV)
+        native.check(native.lib().mg_upfirdn2d_index_table(native.ptr(tab), out, in_size, up, down, pad0, fs, flip,
+                                                           native.stream_ptr(tab.device)))
+        assert np.array_equal(tab.cpu().numpy(), oracle.index_table(out, in_size, up, down, pad0, fs, flip))
+
+
+HOT = [  # (shape, up, down, padding, gain, filter)  -- SURVEY 2.3 call sites and their gradients
+    ([2, 3, 257, 257], 1, 1, [1, 1, 1, 1], 4.0, 'k4'),     # G conv0 post-blur
+    ([2, 3, 256, 256], 1, 1, [2, 2, 2, 2], 1.0, 'k4'),     # D conv1 pre-blur / gradient of the above
+    ([2, 4, 128, 128], 2, 1, [2, 1, 2, 1], 4.0, 'k4'),     # ToRGB image upsample
+    ([2, 3, 256, 256], 1, 2, [1, 1, 1, 1], 1.0, 'k4'),     # D skip downsample
+    ([2, 3, 128, 128], 2, 1, [1, 2, 1, 2], 1.0, 'k4'),     # gradient of the downsample (odd phase)
+    ([3, 5, 65, 33], 1, 1, [1, 1, 1, 1], 4.0, 'k4'),
+    ([3, 5, 17, 17], 1, 1, [1, 1, 1, 1], 4.0, 'k4'),
+    ([2, 7, 16, 16], 1, 2, [1, 1, 1, 1], 1.0, 'k4'),
+    ([2, 7, 8, 8], 2, 1, [2, 1, 2, 1], 4.0, 'k4'),
+    ([1, 2, 100, 70], 1, 1, [1, 1, 0, 0], 1.0, 'k3'),
+    ([1, 2, 70, 100], 2, 1, [3, -1, 0, 2], 1.0, 'k4'),
+    ([2, 3, 134, 140], [2, 1], 1, [6, 5, 0, 0], 2.0, 'r12'),    # ADA separable passes
+    ([2, 3, 140, 134], [1, 2], 1, [0, 0, 6, 5], 2.0, 'c12'),
+    ([2, 3, 140, 268], 1, [2, 1], [5, 5, 0, 0], 1.0, 'r12'),
+    ([2, 3, 268, 140], 1, [1, 2], [0, 0, 5, 5], 1.0, 'c12'),
+    ([2, 3, 64, 64], 1, 1, [6, 5, 0, 0], 1.0, 'r12'),
+    ([1, 1, 40, 40], 3, 2, [2, 2, 2, 2], 1.0, 'k5'),            # generic kernel
+]
+
+
+def _int_filter(kind):
+    k = {'k4': [1, 3, 3, 1], 'k3': [1, 2, 1], 'k5': [1, 4, 6, 4, 1]}
+    if kind in k:
+        v = np.asarray(k[kind], dtype=np.float32)
+        return np.outer(v, v)
+    taps = np.asarray([1, -2, 3, -4, 5, 6, 7, -5, 4, -3, 2, -1], dtype=np.float32)
+    return taps[None, :] if kind == 'r12' else taps[:, None]
+
+
+@pytest.mark.parametrize('flip', [False, True])
+def test_upfirdn2d_integer_data_bit_exact(native, oracle, flip):
+    """Small-integer inputs and taps make every product and partial sum exact in fp32, so ANY error in the
+    index path (which sample meets which tap) shows as a bit difference.  Covers every tiled
+    specialisation, both tile phases and the generic kernel."""
+    rng = np.random.RandomState(5)
+    plugin = custom_ops().get_plugin('upfirdn2d_plugin')
+    for shape, up, down, pad, gain, fk in HOT:
+        x = rng.randint(-8, 9, size=shape).astype(np.float32)
+        f = _int_filter(fk)
+        up2 = (up, up) if isinstance(up, int) else tuple(up)
+        dn2 = (down, down) if isinstance(down, int) else tuple(down)
+        want = oracle.upfirdn2d(x, f, up2, dn2, tuple(pad), flip, gain)
+        got = plugin.upfirdn2d(T(x).to(DEV), T(f).to(DEV), up2[0], up2[1], dn2[0], dn2[1], pad[0], pad[1], pad[2], pad[3],
+                               flip, gain)
+        assert got.shape == want.shape, (shape, up, down, pad)
+        assert np.array_equal(got.cpu().numpy(), want), (shape, up, down, pad, fk, flip)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16, torch.float64])
+def test_upfirdn2d_dtypes_vs_oracle(native, oracle, dtype):
+    rng = np.random.RandomState(11)
+    U = op('upfirdn2d')
+    f = U.setup_filter([1, 3, 3, 1])
+    for shape, kw in [([2, 3, 33, 33], dict(padding=[1, 1, 1, 1], gain=4)), ([2, 4, 16, 16], dict(up=2, padding=[2, 1, 2, 1], gain=4)),
+                      ([2, 3, 32, 32], dict(down=2, padding=[1, 1, 1, 1])), ([1, 2, 9, 11], dict(up=3, down=2, padding=[2, 2, 2, 2]))]:
+        x = T(rng.randn(*shape).astype(np.float32)).to(dtype)
+        want = oracle.upfirdn2d_api(x.to(torch.float64 if dtype == torch.float64 else torch.float32).numpy(), f.numpy(), **kw)
+        got = U.upfirdn2d(x.to(DEV), f.to(DEV), **kw)
+        assert got.dtype == dtype
+        close_lowp(got.double().cpu().numpy(), want, dtype, str((shape, kw)))
+
+
+def test_upfirdn2d_strided_views_and_channels_last(native, oracle):
+    rng = np.random.RandomState(3)
+    U = op('upfirdn2d')
+    f = U.setup_filter([1, 3, 3, 1])
+    big = T(rng.randn(2, 6, 20, 24).astype(np.float32)).to(DEV)
+    view = big[:, 1:5, 2:18, 3:21]                                  # non-dense view -> generic kernel
+    want = oracle.upfirdn2d_api(view.cpu().numpy(), f.numpy(), up=2, padding=[2, 1, 2, 1], gain=4)
+    np.testing.assert_allclose(U.upfirdn2d(view, f.to(DEV), up=2, padding=[2, 1, 2, 1], gain=4).cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    cl = big.contiguous(memory_format=torch.channels_last)
+    y = U.upfirdn2d(cl, f.to(DEV), down=2, padding=[1, 1, 1, 1])
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(y.cpu().numpy(), oracle.upfirdn2d_api(big.cpu().numpy(), f.numpy(), down=2, padding=[1, 1, 1, 1]), rtol=1e-5, atol=1e-5)
+
+
+def test_upfirdn2d_full_size_properties(native):
+    """BASELINE-size tensors (too big for the oracle loop): linearity, DC preservation, and
+    <upfirdn(x), y> == <x, upfirdn^T(y)> (the backward is the adjoint)."""
+    U = op('upfirdn2d')
+    f = U.setup_filter([1, 3, 3, 1]).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn([8, 64, 257, 257], device=DEV, generator=g)
+    z = torch.randn([8, 64, 257, 257], device=DEV, generator=g)
+    kw = dict(padding=[1, 1, 1, 1], gain=4)
+    lin = U.upfirdn2d(2 * x - 3 * z, f, **kw) - (2 * U.upfirdn2d(x, f, **kw) - 3 * U.upfirdn2d(z, f, **kw))
+    assert float(lin.abs().max()) < 2e-4
+    ones = torch.ones([2, 4, 128, 128], device=DEV)
+    up = U.upsample2d(ones, f)
+    assert up.shape == (2, 4, 256, 256)
+    assert float((up[:, :, 4:-4, 4:-4] - 1).abs().max()) < 1e-6
+    xr = x[:2].clone().requires_grad_(True)
+    y = U.upfirdn2d(xr, f, down=2, padding=[1, 1, 1, 1])
+    w = torch.randn(y.shape, device=DEV, generator=g)
+    gx, = torch.autograd.grad([y], [xr], [w])
+    lhs, rhs = float((y.detach().double() * w.double()).sum()), float((xr.detach().double() * gx.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+def test_upfirdn2d_errors(native):
+    U = op('upfirdn2d')
+    plugin = custom_ops().get_plugin('upfirdn2d_plugin')
+    x = torch.zeros([1, 1, 4, 4], device=DEV)
+    f = torch.ones([2, 2], device=DEV)
+    with pytest.raises(RuntimeError, match='output must be at least 1x1'):
+        plugin.upfirdn2d(x, torch.ones([8, 8], device=DEV), 1, 1, 1, 1, 0, 0, 0, 0, False, 1.0)
+    with pytest.raises(RuntimeError, match='f must be float32'):
+        plugin.upfirdn2d(x, f.double(), 1, 1, 1, 1, 0, 0, 0, 0, False, 1.0)
+    with pytest.raises(RuntimeError, match='x must be rank 4'):
+        plugin.upfirdn2d(x[0], f, 1, 1, 1, 1, 0, 0, 0, 0, False, 1.0)
+    with pytest.raises(RuntimeError, match='x must reside on CUDA device'):
+        plugin.upfirdn2d(x.cpu(), f.cpu(), 1, 1, 1, 1, 0, 0, 0, 0, False, 1.0)
+    # empty batch is legal
+    assert U.upfirdn2d(torch.zeros([0, 3, 8, 8], device=DEV), f, padding=1).shape == (0, 3, 9, 9)
+
+
+# --------------------------------------------------------------------------------------------
+# bias_act
+
+def test_bias_act_golden_all_orders(native):
+    B = op('bias_act')
+    cases, arr = load_golden('bias_act')
+    before = native.launch_count(native.K_BIAS_ACT)
+    for c in cases:
+        i = c['id']
+        out = run_bias_act_case(B, c, arr, device=DEV, impl='cuda')
+        x = arr[f'c{i}_x']
+        b = arr[f'c{i}_b'] if c['with_b'] else None
+        dim = c['dim']
+        pre = x + (0 if b is None else b.reshape([-1 if k == dim else 1 for k in range(x.ndim)]))
+        mask = np.ones(x.shape, bool)
+        if c['act'] in ('relu', 'lrelu', 'elu', 'selu'):
+            mask &= np.abs(pre) > 1e-6           # one-sided derivative at the kink: kernel vs aten convention
+        if c['clamp'] is not None:
+            mask &= np.abs(np.abs(arr[f'c{i}_y']) - c['clamp']) > 1e-5
+        tol = dict(rtol=2e-4, atol=2e-5) if c['dtype'] == 'float32' else dict(rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(out['y'].detach().cpu().numpy(), arr[f'c{i}_y'], err_msg=str(c), **tol)
+        np.testing.assert_allclose(out['dx'].detach().cpu().numpy()[mask], arr[f'c{i}_dx'][mask], err_msg=str(c), **tol)
+        if out['db'] is not None and mask.all():
+            np.testing.assert_allclose(out['db'].detach().cpu().numpy(), arr[f'c{i}_db'], err_msg=str(c), rtol=1e-3, atol=1e-4)
+        if 'g2x' in out:
+            np.testing.assert_allclose(out['g2dy'].cpu().numpy()[mask], arr[f'c{i}_g2dy'][mask], err_msg=str(c), **tol)
+            np.testing.assert_allclose(out['g2x'].cpu().numpy()[mask], arr[f'c{i}_g2x'][mask], err_msg=str(c), rtol=1e-3, atol=1e-4)
+    assert native.launch_count(native.K_BIAS_ACT) - before >= 2 * len(cases)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('memfmt', ['contiguous', 'channels_last'])
+def test_bias_act_raw_vs_oracle(native, oracle, dtype, memfmt):
+    """Plugin-level call on every vector/bias-index path: aligned + step_b % VEC == 0 (NCHW), bias per
+    element (NHWC / odd planes), tails, all three gradient orders."""
+    rng = np.random.RandomState(17)
+    plugin = custom_ops().get_plugin('bias_act_plugin')
+    null = torch.empty([0])
+    for shape in ([2, 6, 8, 8], [3, 5, 7, 9], [2, 16, 4, 4], [4, 512], [1, 3, 1, 5]):
+        if memfmt == 'channels_last' and len(shape) != 4:
+            continue
+        x = T(rng.randn(*shape).astype(np.float32) * 2).to(dtype).to(DEV)
+        xr = T(rng.randn(*shape).astype(np.float32)).to(dtype).to(DEV)
+        yr = T(rng.randn(*shape).astype(np.float32)).to(dtype).to(DEV)
+        dy = T(rng.randn(*shape).astype(np.float32)).to(dtype).to(DEV)
+        b = T(rng.randn(shape[1]).astype(np.float32)).to(dtype).to(DEV)
+        if memfmt == 'channels_last':
+            x, xr, yr, dy = (t.contiguous(memory_format=torch.channels_last) for t in (x, xr, yr, dy))
+
+        def phys(t):   # dense physical order, as the kernel sees it
+            t = t.float().cpu()
+            return (t.permute(0, 2, 3, 1) if memfmt == 'channels_last' else t).contiguous().numpy()
+
+        dim_phys = 3 if memfmt == 'channels_last' else 1
+        for act in (1, 3, 5, 9):
+            for grad in (0, 1, 2):
+                if grad == 2 and act in (1, 3):
+                    continue
+                got = plugin.bias_act(x, b, xr if grad else null, yr if grad else null, dy if grad == 2 else null, grad, 1, act,
+                                      0.2, 1.4142135, 1.5)
+                assert got.stride() == x.stride()
+                want = oracle.bias_act_raw(phys(x), b.float().cpu().numpy(), phys(xr) if grad else None, phys(yr) if grad else None,
+                                           phys(dy) if grad == 2 else None, grad=grad, dim=dim_phys, act=act, alpha=0.2,
+                                           gain=1.4142135, clamp=1.5)
+                close_lowp(phys(got), want, dtype, f'{shape} act {act} grad {grad} {memfmt}')
+
+
+def test_bias_act_unaligned_and_empty(native, oracle):
+    plugin = custom_ops().get_plugin('bias_act_plugin')
+    null = torch.empty([0])
+    base = torch.randn([1003], device=DEV)
+    x = base[1:].reshape(1, 2, 501)             # storage offset 4 bytes -> not 16-byte aligned
+    b = torch.randn([2], device=DEV)
+    got = plugin.bias_act(x, b, null, null, null, 0, 1, 3, 0.2, 1.0, -1.0)
+    want = oracle.bias_act_raw(x.cpu().numpy(), b.cpu().numpy(), grad=0, dim=1, act=3, alpha=0.2, gain=1.0, clamp=-1.0)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+    B = op('bias_act')
+    assert B.bias_act(torch.zeros([0, 4, 2, 2], device=DEV), torch.zeros([4], device=DEV), act='lrelu').shape == (0, 4, 2, 2)
+    with pytest.raises(RuntimeError, match='b has wrong number of elements'):
+        plugin.bias_act(torch.zeros([2, 3], device=DEV), torch.zeros([4], device=DEV), null, null, null, 0, 1, 1, 0.0, 1.0, -1.0)
+
+
+def test_bias_act_full_size_properties(native):
+    B = op('bias_act')
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn([16, 64, 256, 256], device=DEV, generator=g)
+    b = torch.randn([64], device=DEV, generator=g)
+    y = B.bias_act(x, b, act='lrelu', clamp=256)
+    ref = torch.nn.functional.leaky_relu(x + b.reshape(1, -1, 1, 1), 0.2) * np.sqrt(2)
+    assert float((y - ref.clamp(-256, 256)).abs().max()) < 1e-5
+    # idempotence of the clamp stage and oddness of lrelu-with-alpha-1
+    z = B.bias_act(x, None, act='lrelu', alpha=1.0, gain=1.0)
+    assert torch.equal(z, x)
+
+
+# --------------------------------------------------------------------------------------------
+# conv2d_resample / modulated conv building blocks on the GPU (aten convs + native resampling)
+
+@pytest.mark.parametrize('gradfix', [False, True])
+def test_conv2d_resample_golden_on_gpu(native, gradfix):
+    cases, arr = load_golden('conv')
+    for c in cases:
+        out = run_conv_case(c, arr, device=DEV, gradfix=gradfix)
+        if out is None:
+            continue
+        for k, v in out.items():
+            np.testing.assert_allclose(v.detach().cpu().numpy(), arr[f'c{c["id"]}_{k}'], rtol=1e-3, atol=1e-3, err_msg=f'{c} {k}')
+
+
+# --------------------------------------------------------------------------------------------
+# fused epilogue, filtered_lrelu
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+def test_modconv_epilogue_matches_fma_then_bias_act(native, dtype):
+    E, B, F = op('modconv_epilogue'), op('bias_act'), op('fma')
+    g = torch.Generator(device=DEV).manual_seed(2)
+    for shape in ([2, 6, 16, 16], [3, 5, 7, 9]):
+        n, c, h, w = shape
+        x = torch.randn(shape, device=DEV, generator=g).to(dtype).requires_grad_(True)
+        d = (torch.rand([n, c], device=DEV, generator=g) + 0.5).requires_grad_(True)
+        nz = (torch.randn([h, w], device=DEV, generator=g) * 0.1).requires_grad_(True)
+        b = torch.randn([c], device=DEV, generator=g).requires_grad_(True)
+        before = native.launch_count(native.K_FMA_BIAS_ACT)
+        y = E.modconv_epilogue(x, d, nz, b, act='lrelu', clamp=256)
+        assert native.launch_count(native.K_FMA_BIAS_ACT) == before + 1
+        t = F.fma(x, d.to(dtype).reshape(n, c, 1, 1), nz.to(dtype))
+        y2 = B.bias_act(t, b.to(dtype), act='lrelu', clamp=256)
+        close_lowp(y.float().detach().cpu().numpy(), y2.float().detach().cpu().numpy(), dtype, 'fwd')
+        dy = torch.randn(shape, device=DEV, generator=g).to(dtype)
+        g1 = torch.autograd.grad([y], [x, d, nz, b], [dy])
+        g2 = torch.autograd.grad([y2], [x, d, nz, b], [dy])
+        for u, v, nm in zip(g1, g2, 'x d noise b'.split()):
+            close_lowp(u.float().cpu().numpy(), v.float().cpu().numpy(), dtype, f'grad {nm}')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_filtered_lrelu_matches_composition(native, dtype):
+    FL, U = op('filtered_lrelu'), op('upfirdn2d')
+    g = torch.Generator(device=DEV).manual_seed(3)
+    f4 = U.setup_filter([1, 3, 3, 1]).to(DEV)
+    f12 = U.setup_filter(list(np.hanning(14)[1:-1])).to(DEV)
+    for shape, up, down, fu, fd, pad in [([2, 3, 32, 32], 2, 2, f4, f4, [2, 1, 2, 1]), ([1, 4, 40, 24], 2, 1, f12, None, 6),
+                                         ([2, 2, 50, 70], 1, 2, None, f12, 0), ([2, 3, 33, 35], 2, 2, f12, f12, [8, 7, 8, 7])]:
+        x = torch.randn(shape, device=DEV, generator=g).to(dtype)
+        b = torch.randn([shape[1]], device=DEV, generator=g).to(dtype)
+        before = native.launch_count(native.K_FILTERED_LRELU)
+        with torch.no_grad():
+            y = FL.filtered_lrelu(x, fu, fd, b, up=up, down=down, padding=pad, clamp=2.0)
+        assert native.launch_count(native.K_FILTERED_LRELU) == before + 1
+        ref = FL.filtered_lrelu(x, fu, fd, b, up=up, down=down, padding=pad, clamp=2.0, impl='ref')
+        assert y.shape == ref.shape
+        close_lowp(y.float().cpu().numpy(), ref.float().cpu().numpy(), dtype, str((shape, up, down)))
+
+
+# --------------------------------------------------------------------------------------------
+# alpha composite, translate sample
+
+def test_alpha_composite_golden_and_oracle(native, oracle):
+    A = op('alpha_composite')
+    cases, arr = load_golden('montage')
+    x = T(arr['png_layers_u8'].astype(np.float32) / 255.0).to(DEV)
+    np.testing.assert_allclose(A.alpha_composite(x).cpu().numpy(), arr['png_out'], rtol=1e-5, atol=1e-6)
+    for c in cases:
+        if c['op'] != 'alpha_composite' or c['src'] != 'rand':
+            continue
+        i = c['id']
+        x = T(arr[f'c{i}_x']).to(DEV).requires_grad_(True)
+        y = A.alpha_composite(x)
+        dx, = torch.autograd.grad([y], [x], [T(arr[f'c{i}_dy']).to(DEV)])
+        np.testing.assert_allclose(y.detach().cpu().numpy(), arr[f'c{i}_y'], rtol=1e-5, atol=1e-6, err_msg=str(c))
+        ref = arr[f'c{i}_dx']
+        got = dx.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), c
+        np.testing.assert_allclose(got, ref, rtol=1e-3, atol=2e-4, equal_nan=True, err_msg=str(c))
+        y2 = A.alpha_composite(x, safe_grad=True)
+        dx2, = torch.autograd.grad([y2], [x], [T(arr[f'c{i}_dy']).to(DEV)])
+        assert bool(torch.isfinite(dx2).all())
+    # odd pixel count -> scalar path; half precision
+    rng = np.random.RandomState(4)
+    x = rng.rand(2, 5, 4, 7, 9).astype(np.float32)
+    for dtype in (torch.float32, torch.float16, torch.bfloat16):
+        xt = T(x).to(dtype)
+        want = oracle.alpha_composite(xt.float().numpy())
+        close_lowp(A.alpha_composite(xt.to(DEV)).float().cpu().numpy(), want, dtype, 'composite')
+
+
+def test_alpha_composite_full_size_properties(native):
+    A = op('alpha_composite')
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.rand([4, 8, 4, 256, 256], device=DEV, generator=g)
+    y = A.alpha_composite(x)
+    assert y.shape == (4, 4, 256, 256)
+    # an opaque top layer hides everything below; a transparent one changes nothing
+    top = x.clone(); top[:, -1, 3] = 1.0
+    assert torch.allclose(A.alpha_composite(top)[:, :3], top[:, -1, :3], atol=1e-6)
+    clear = x.clone(); clear[:, -1, 3] = 0.0
+    assert torch.allclose(A.alpha_composite(clear), A.alpha_composite(x[:, :-1]), atol=1e-6)
+    assert torch.allclose(y, A.alpha_composite(x, impl='ref'), atol=1e-5)
+
+
+def test_translate_sample_golden_and_oracle(native, oracle):
+    TS = op('translate_sample')
+    cases, arr = load_golden('montage')
+    for c in cases:
+        if c['op'] != 'translate_sample':
+            continue
+        i = c['id']
+        b, l, ch, h, w = c['shape']
+        x = T(arr[f'c{i}_x']).reshape(b * l, ch, h, w).to(DEV).requires_grad_(True)
+        t = T(arr[f'c{i}_t']).reshape(b * l, 2).to(DEV).requires_grad_(True)
+        y = TS.translate_sample(x, t, shift=c['shift'])
+        dx, dt = torch.autograd.grad([y], [x, t], [T(arr[f'c{i}_dy']).to(DEV)])
+        np.testing.assert_allclose(y.detach().cpu().numpy(), arr[f'c{i}_y'], rtol=1e-4, atol=1e-4, err_msg=str(c))
+        np.testing.assert_allclose(dx.cpu().numpy(), arr[f'c{i}_dx'].reshape(x.shape), rtol=1e-4, atol=1e-4, err_msg=str(c))
+        np.testing.assert_allclose(dt.cpu().numpy(), arr[f'c{i}_dt'].reshape(-1, 2), rtol=2e-3, atol=2e-3, err_msg=str(c))
+    # integer-pixel and half-pixel shifts, exact texel boundaries, out-of-frame
+    rng = np.random.RandomState(6)
+    x = rng.randn(6, 4, 32, 48).astype(np.float32)
+    t = np.asarray([[0, 0], [2 / 48, -4 / 32], [1 / 48, 1 / 32], [-0.5, 0.25], [2.5, 0], [0.3333, -0.7777]], dtype=np.float32)
+    dy = rng.randn(*x.shape).astype(np.float32)
+    for shift in (0.0, 1.0):
+        xt, tt = T(x).to(DEV).requires_grad_(True), T(t).to(DEV).requires_grad_(True)
+        y = TS.translate_sample(xt, tt, shift=shift)
+        gx, gt = torch.autograd.grad([y], [xt, tt], [T(dy).to(DEV)])
+        np.testing.assert_allclose(y.detach().cpu().numpy(), oracle.translate_sample(x, t, shift), rtol=1e-5, atol=1e-5)
+        odx, odt = oracle.translate_sample_bwd(x, dy, t, shift)
+        np.testing.assert_allclose(gx.cpu().numpy(), odx, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(gt.cpu().numpy(), odt, rtol=1e-3, atol=1e-2)
+
+
+def test_translate_sample_full_size_properties(native):
+    TS = op('translate_sample')
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x = torch.randn([32, 4, 256, 256], device=DEV, generator=g)
+    zero = torch.zeros([32, 2], device=DEV)
+    assert torch.allclose(TS.translate_sample(x, zero, shift=1.0), x, atol=1e-6)        # identity
+    t = (torch.rand([32, 2], device=DEV, generator=g) - 0.5)
+    y = TS.translate_sample(x, t, shift=1.0)
+    assert torch.allclose(y, TS.translate_sample(x, t, shift=1.0, impl='ref'), atol=1e-4)
+    # adjoint: <S x, w> == <x, S^T w>
+    xr = x.clone().requires_grad_(True)
+    w = torch.randn(x.shape, device=DEV, generator=g)
+    gx, = torch.autograd.grad([TS.translate_sample(xr, t)], [xr], [w])
+    lhs = float((TS.translate_sample(x, t).double() * w.double()).sum())
+    rhs = float((x.double() * gx.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+def test_profiling_hooks_report_kernel_time(native):
+    B = op('bias_act')
+    x = torch.randn([8, 64, 128, 128], device=DEV)
+    native.prof_reset()
+    native.prof_enable(True)
+    try:
+        for _ in range(5):
+            B.bias_act(x, None, act='lrelu')
+        torch.cuda.synchronize()
+        rec = native.prof_collect()
+    finally:
+        native.prof_enable(False)
+        native.prof_reset()
+    assert rec['bias_act']['launches'] == 5
+    assert rec['bias_act']['ms'] > 0
+    assert rec['bias_act']['bytes'] == 5 * 2 * x.numel() * 4
