@@ -44,6 +44,19 @@ def _has_same_layout(a, b):
     return True
 
 
+def _is_non_overlapping_and_dense(t):
+    """at::Tensor::is_non_overlapping_and_dense(): some permutation of the dims is contiguous."""
+    if t.numel() <= 1 or t.is_contiguous():
+        return True
+    dims = sorted((d for d in range(t.dim()) if t.size(d) != 1), key=lambda d: t.stride(d))
+    expect = 1
+    for d in dims:
+        if t.stride(d) != expect:
+            return False
+        expect *= t.size(d)
+    return True
+
+
 def _require(cond, msg):
     if not cond:
         raise RuntimeError(msg)
@@ -74,6 +87,8 @@ class _Upfirdn2dPlugin:
         _require(ow >= 1 and oh >= 1, 'output must be at least 1x1')                           # :34
         y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device, memory_format=_suggest_memory_format(x))
         _require(y.numel() <= 2 ** 31 - 1, 'output is too large')                              # :36
+        if y.numel() == 0:
+            return y
         with torch.cuda.device(x.device):
             rc = native.lib().mg_upfirdn2d(
                 native.ptr(x), native.ptr(f), native.ptr(y), native.dtype_code(x.dtype),
@@ -104,13 +119,15 @@ class _BiasActPlugin:
         _require(_is_null(b) or (0 <= dim < x.dim()), 'dim is out of bounds')                  # :42
         _require(_is_null(b) or b.numel() == x.size(dim), 'b has wrong number of elements')    # :43
         _require(grad >= 0, 'grad must be non-negative')                                       # :44
-        _require(x.is_non_overlapping_and_dense(), 'x must be non-overlapping and dense')      # :47
+        _require(_is_non_overlapping_and_dense(x), 'x must be non-overlapping and dense')      # :47
         _require(_is_null(b) or b.is_contiguous(), 'b must be contiguous')                     # :48
         for t, name in ((xref, 'xref'), (yref, 'yref'), (dy, 'dy')):
             _require(_is_null(t) or _has_same_layout(t, x), f'{name} must have the same layout as x')  # :49-51
         y = torch.empty_like(x)
         _require(_has_same_layout(y, x), 'y must have the same layout as x')                   # :56
         has_b = not _is_null(b)
+        if x.numel() == 0:
+            return y
         with torch.cuda.device(x.device):
             rc = native.lib().mg_bias_act(
                 native.ptr(x), native.ptr(b if has_b else None),

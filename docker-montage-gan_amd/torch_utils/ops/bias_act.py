@@ -155,5 +155,6 @@ def _bias_act_cuda(dim=1, act='linear', alpha=None, gain=None, clamp=None):
                 d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
             return d_dy, d_x, d_b, None
 
+    BiasActCuda.Grad = BiasActCudaGrad      # first-order gradient op, itself differentiable (used by modconv_epilogue)
     _bias_act_cuda_cache[key] = BiasActCuda
     return BiasActCuda
