@@ -15,6 +15,7 @@ namespace {
 template <class T> struct FbArgs {
     const T* x; const float* d; const float* noise; const T* b; T* y; T* y2;
     float alpha, gain, clamp, noise_gain;
+    int64_t noise_stride_n;
     uint32_t c, hw, total_vec;
     FastDiv hwv_div, c_div;     // hw/VEC and C
 };
@@ -31,12 +32,14 @@ __global__ void __launch_bounds__(256) fma_bias_act_fwd_kernel(FbArgs<T> p)
         V xin = ((const V*)p.x)[vi];
         float dc = p.d ? p.d[plane] : 1.f;
         float bb = 0.f;
-        if (p.b) { uint32_t n = fd_div(plane, p.c_div); bb = to_acc<T>(p.b[plane - n * p.c]); }
+        const uint32_t n = fd_div(plane, p.c_div);
+        if (p.b) bb = to_acc<T>(p.b[plane - n * p.c]);
+        const float* nz = p.noise ? p.noise + (int64_t)n * p.noise_stride_n + (size_t)pv * VEC : nullptr;
         V out;
         #pragma unroll
         for (int e = 0; e < VEC; e++) {
             float v = to_acc<T>(xin.v[e]) * dc;
-            if (p.noise) v += p.noise[pv * VEC + e] * p.noise_gain;
+            if (nz) v += nz[e] * p.noise_gain;
             // the reference rounds the fma result to T before bias_act reads it back
             v = to_acc<T>(from_acc<T>(v));
             out.v[e] = from_acc<T>(ba_eval<float, A>(0, v, bb, 0.f, 0.f, 1.f, k));
@@ -113,7 +116,7 @@ int dispatch_fb(const FbArgs<T>& p, int act, bool bwd, bool wide, hipStream_t s)
 //   out   : decimating FIR of s_mid, straight to global
 constexpr int FL_TW = 32, FL_TH = 32, FL_MAXF = 12;
 constexpr int FL_MIDW = FL_TW * 2 + FL_MAXF - 1, FL_MIDH = FL_TH * 2 + FL_MAXF - 1;   // worst case down=2
-constexpr int FL_INW = FL_MIDW + FL_MAXF, FL_INH = FL_MIDH + FL_MAXF;                 // worst case up=1
+
 
 struct FlArgs {
     const void* x; const void* b; const float* fu; const float* fd; void* y;
@@ -193,8 +196,8 @@ __global__ void __launch_bounds__(256) filtered_lrelu_kernel(FlArgs p)
 } // namespace
 
 extern "C" int mg_fma_bias_act(const void* x, const float* d, const float* noise, const void* b, void* y, int dtype,
-                               int act, float alpha, float gain, float clamp, float noise_gain, int32_t n, int32_t c,
-                               int32_t hw, void* stream)
+                               int act, float alpha, float gain, float clamp, float noise_gain,
+                               int64_t noise_stride_n, int32_t n, int32_t c, int32_t hw, void* stream)
 {
     MG_REQUIRE(x && y, "x must reside on the device");
     MG_REQUIRE(dtype == MG_F32 || dtype == MG_F16 || dtype == MG_BF16, "fma_bias_act: unsupported dtype %d", dtype);
@@ -211,7 +214,7 @@ extern "C" int mg_fma_bias_act(const void* x, const float* d, const float* noise
         if (sizeof(T) == 8) break;
         FbArgs<T> p;
         p.x = (const T*)x; p.d = d; p.noise = noise; p.b = (const T*)b; p.y = (T*)y; p.y2 = nullptr;
-        p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_gain = noise_gain;
+        p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_gain = noise_gain; p.noise_stride_n = noise_stride_n;
         p.c = (uint32_t)c; p.hw = (uint32_t)hw; p.total_vec = (uint32_t)total; p.c_div = make_fastdiv((uint32_t)c);
         rc = dispatch_fb<T>(p, act, false, wide, s);
     });
@@ -238,7 +241,7 @@ extern "C" int mg_fma_bias_act_bwd(const void* dy, const void* yref, const float
         if (sizeof(T) == 8) break;
         FbArgs<T> p;
         p.x = (const T*)dy; p.d = d; p.noise = nullptr; p.b = (const T*)yref; p.y = (T*)dx; p.y2 = (T*)dpre;
-        p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_gain = 0.f;
+        p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_gain = 0.f; p.noise_stride_n = 0;
         p.c = (uint32_t)c; p.hw = (uint32_t)hw; p.total_vec = (uint32_t)total; p.c_div = make_fastdiv((uint32_t)c);
         rc = dispatch_fb<T>(p, act, true, wide, s);
     });

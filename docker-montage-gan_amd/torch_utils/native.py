@@ -50,7 +50,7 @@ def _declare(L):
     L.mg_bias_act.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                               c_float, c_float, c_float, c_i64, c_i32, c_i64, c_void_p]
     L.mg_fma_bias_act.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
-                                  c_float, c_float, c_i32, c_i32, c_i32, c_void_p]
+                                  c_float, c_float, c_i64, c_i32, c_i32, c_i32, c_void_p]
     L.mg_fma_bias_act_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
                                       c_float, c_i32, c_i32, c_i32, c_void_p]
     L.mg_alpha_composite_fwd.argtypes = [c_void_p, c_void_p, c_int, c_i32, c_i32, c_i32, c_i32, c_void_p]

@@ -115,8 +115,9 @@ int mg_bias_act(const void* x, const void* b, const void* xref, const void* yref
                 int64_t size_x, int32_t size_b, int64_t step_b, void* stream);
 
 /* ---- fused modulated-conv epilogue ----------------------------------------
- * y = clamp(act(x * d[n,c] + noise[h,w] * noise_gain + b[c]) * gain), NCHW
- * contiguous; d (float32 [N,C]), noise (float32 [H*W]) and b may each be NULL.
+ * y = clamp(act(x * d[n,c] + noise[n,h,w] * noise_gain + b[c]) * gain), NCHW
+ * contiguous; d (float32 [N,C]), noise (float32, sample n at noise + n*noise_stride_n:
+ * stride 0 = one [H*W] map shared by the batch, H*W = per-sample maps) and b may each be NULL.
  * One read and one write of x instead of the three round trips of
  * fma.fma + bias_act.bias_act (training/networks.py:86-88, 311-313).
  * mg_fma_bias_act_bwd: dx_pre = dy * act'(yref) * gain masked by the clamp
@@ -124,7 +125,8 @@ int mg_bias_act(const void* x, const void* b, const void* xref, const void* yref
  * `dpre` is non NULL, dx_pre itself (needed for d(d), d(noise), d(b) sums).    */
 int mg_fma_bias_act(const void* x, const float* d, const float* noise, const void* b,
                     void* y, int dtype, int act, float alpha, float gain, float clamp,
-                    float noise_gain, int32_t n, int32_t c, int32_t hw, void* stream);
+                    float noise_gain, int64_t noise_stride_n,
+                    int32_t n, int32_t c, int32_t hw, void* stream);
 int mg_fma_bias_act_bwd(const void* dy, const void* yref, const float* d,
                         void* dx, void* dpre, int dtype, int act, float alpha,
                         float gain, float clamp, int32_t n, int32_t c, int32_t hw,

@@ -406,10 +406,15 @@ def test_translate_sample_golden_and_oracle(native, oracle):
         np.testing.assert_allclose(y.detach().cpu().numpy(), arr[f'c{i}_y'], rtol=1e-4, atol=1e-4, err_msg=str(c))
         np.testing.assert_allclose(dx.cpu().numpy(), arr[f'c{i}_dx'].reshape(x.shape), rtol=1e-4, atol=1e-4, err_msg=str(c))
         np.testing.assert_allclose(dt.cpu().numpy(), arr[f'c{i}_dt'].reshape(-1, 2), rtol=2e-3, atol=2e-3, err_msg=str(c))
-    # integer-pixel and half-pixel shifts, exact texel boundaries, out-of-frame
+    # integer-pixel and half-pixel shifts (exact texel boundaries), out-of-frame, generic
     rng = np.random.RandomState(6)
-    x = rng.randn(6, 4, 32, 48).astype(np.float32)
-    t = np.asarray([[0, 0], [2 / 48, -4 / 32], [1 / 48, 1 / 32], [-0.5, 0.25], [2.5, 0], [0.3333, -0.7777]], dtype=np.float32)
+    x = rng.randn(8, 4, 32, 48).astype(np.float32)
+    t = np.asarray([[0, 0], [2 / 48, -4 / 32], [1 / 48, 1 / 32], [-0.5, 0.25], [2.5, 0], [0.3333, -0.7777],
+                    [-0.1234, 0.0577], [0.9, 0.41]], dtype=np.float32)
+    # d/dt is discontinuous where a sample lands exactly on a texel (left and right slopes differ and
+    # the float rounding of the coordinate picks one per pixel -- in the reference too), so it is
+    # compared only for shifts that are not a whole number of pixels; y and dx are continuous.
+    smooth = [2, 5, 6, 7]
     dy = rng.randn(*x.shape).astype(np.float32)
     for shift in (0.0, 1.0):
         xt, tt = T(x).to(DEV).requires_grad_(True), T(t).to(DEV).requires_grad_(True)
@@ -418,7 +423,8 @@ def test_translate_sample_golden_and_oracle(native, oracle):
         np.testing.assert_allclose(y.detach().cpu().numpy(), oracle.translate_sample(x, t, shift), rtol=1e-5, atol=1e-5)
         odx, odt = oracle.translate_sample_bwd(x, dy, t, shift)
         np.testing.assert_allclose(gx.cpu().numpy(), odx, rtol=1e-5, atol=1e-5)
-        np.testing.assert_allclose(gt.cpu().numpy(), odt, rtol=1e-3, atol=1e-2)
+        np.testing.assert_allclose(gt.cpu().numpy()[smooth], odt[smooth], rtol=1e-3, atol=1e-2)
+        assert np.isfinite(gt.cpu().numpy()).all()
 
 
 def test_translate_sample_full_size_properties(native):
@@ -426,7 +432,8 @@ def test_translate_sample_full_size_properties(native):
     g = torch.Generator(device=DEV).manual_seed(7)
     x = torch.randn([32, 4, 256, 256], device=DEV, generator=g)
     zero = torch.zeros([32, 2], device=DEV)
-    assert torch.allclose(TS.translate_sample(x, zero, shift=1.0), x, atol=1e-6)        # identity
+    # identity up to the float32 rounding of the sampling coordinate (~2.5e-5 px at 256) times the local slope
+    assert torch.allclose(TS.translate_sample(x, zero, shift=1.0), x, atol=1e-3)
     t = (torch.rand([32, 2], device=DEV, generator=g) - 0.5)
     y = TS.translate_sample(x, t, shift=1.0)
     assert torch.allclose(y, TS.translate_sample(x, t, shift=1.0, impl='ref'), atol=1e-4)
