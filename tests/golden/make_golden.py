@@ -306,9 +306,99 @@ def gen_montage():
     save('montage', arrays, dict(cases=cases))
 
 
+# ----------------------------------------------------------------------------
+def _sd(prefix, module, arrays):
+    for k, v in module.state_dict().items():
+        arrays[f'{prefix}.{k}'] = v.detach().clone()
+
+
+def gen_nets():
+    """Small end-to-end networks with their weights: generator image (train + eval paths),
+    discriminator logits, and the gradients every loss phase leaves on the parameters
+    (training/networks.py, training/loss.py; custom/networks_aio.py for the aio variants)."""
+    from training import networks as NW
+    from training import loss as LS
+    from custom import networks_aio as NA
+    arrays, cases = {}, []
+    torch.manual_seed(2024)
+    gk = dict(z_dim=32, w_dim=32, img_resolution=32, img_channels=4, mapping_kwargs=dict(num_layers=2),
+              synthesis_kwargs=dict(channel_base=256, channel_max=16, num_fp16_res=0, conv_clamp=256))
+    dk = dict(img_resolution=32, img_channels=4, channel_base=256, channel_max=16, num_fp16_res=0, conv_clamp=256,
+              epilogue_kwargs=dict(mbstd_group_size=2))
+    G, D = NW.Generator(**gk), NW.Discriminator(**dk)
+    # give the noise strengths / biases non-trivial values so that every term is exercised
+    with torch.no_grad():
+        for n_, p_ in list(G.named_parameters()) + list(D.named_parameters()):
+            if n_.endswith('noise_strength'):
+                p_.fill_(0.3)
+            elif n_.endswith('bias') and 'affine' not in n_:
+                p_.normal_(0, 0.2)
+    _sd('G', G, arrays); _sd('D', D, arrays)
+    z = torch.randn([4, 32])
+    arrays['z'] = z
+    G.train(); D.train()
+    img_train = G(z, noise_mode='const')
+    G.eval()
+    img_eval = G(z, noise_mode='const')
+    img_trunc = G(z, truncation_psi=0.5, noise_mode='const')
+    G.train()
+    arrays['img_train'], arrays['img_eval'], arrays['img_trunc'] = img_train, img_eval, img_trunc
+    arrays['w_avg_after'] = G.mapping.w_avg.detach().clone()
+    arrays['logits'] = D(img_train.detach())
+    cases.append(dict(id=0, op='forward', G_kwargs=gk, D_kwargs=dk))
+
+    # loss phases from a fixed seed; all on CPU, default (random) noise
+    real = torch.randn([4, 4, 32, 32])
+    arrays['real'] = real
+    for pi, phase in enumerate(['Gmain', 'Greg', 'Dmain', 'Dreg', 'Gboth', 'Dboth']):
+        G.load_state_dict({k[2:]: v for k, v in arrays.items() if k.startswith('G.')})
+        D.load_state_dict({k[2:]: v for k, v in arrays.items() if k.startswith('D.')})
+        G.requires_grad_(phase[0] == 'G'); D.requires_grad_(phase[0] == 'D')
+        for p_ in list(G.parameters()) + list(D.parameters()):
+            p_.grad = None
+        loss = LS.StyleGAN2Loss(device=torch.device('cpu'), G_mapping=G.mapping, G_synthesis=G.synthesis, D=D,
+                                augment_pipe=None, style_mixing_prob=0.9, r1_gamma=10, pl_batch_shrink=2, pl_decay=0.01, pl_weight=2)
+        torch.manual_seed(1000 + pi)
+        gen_z = torch.randn([4, 32])
+        arrays[f'p{pi}_gen_z'] = gen_z
+        loss.accumulate_gradients(phase=phase, real_img=real, gen_z=gen_z, sync=True, gain=2.0,
+                                  real_c=torch.zeros([4, 0]), gen_c=torch.zeros([4, 0]))   # c_dim = 0: empty labels, as the base loop passes
+        mod = G if phase[0] == 'G' else D
+        names, sums, abss = [], [], []
+        for n_, p_ in mod.named_parameters():
+            if p_.grad is not None:
+                names.append(n_); sums.append(float(p_.grad.double().sum())); abss.append(float(p_.grad.double().abs().sum()))
+        arrays[f'p{pi}_grad_sum'] = np.asarray(sums); arrays[f'p{pi}_grad_abs'] = np.asarray(abss)
+        first = [n_ for n_ in names if n_.endswith('b16.conv1.weight') or n_.endswith('b16.conv0.weight')][0]
+        arrays[f'p{pi}_grad_sample'] = dict(mod.named_parameters())[first].grad
+        arrays[f'p{pi}_pl_mean'] = loss.pl_mean
+        cases.append(dict(id=1 + pi, op='loss_phase', phase=phase, seed=1000 + pi, gain=2.0, grad_names=names, sample_name=first))
+
+    # aio variants: synthesis from 8x8 (conv_config_index 3), global mapping network, matching discriminator
+    torch.manual_seed(77)
+    sk = dict(w_dim=32, img_resolution=64, img_channels=4, init_res=[8, 8], conv_config_index=3, channel_base=256,
+              channel_max=16, num_fp16_res=0, conv_clamp=256)
+    S = NA.SynthesisNetwork(**sk)
+    M = NA.GlobalMappingNetwork(z_dim=32, w_dim=32, num_ws=S.num_ws, num_splits=3, num_layers=2)
+    Dk = dict(img_resolution=64, img_channels=4, init_res=[8, 8], conv_config_index=3, channel_base=256, channel_max=16,
+              num_fp16_res=0, conv_clamp=256)
+    DA = NA.Discriminator(**Dk)
+    _sd('S', S, arrays); _sd('M', M, arrays); _sd('DA', DA, arrays)
+    z2 = torch.randn([2, 32])
+    arrays['aio_z'] = z2
+    M.train(); S.train(); DA.train()
+    ws = M(z2)
+    arrays['aio_ws'] = ws
+    imgs = [S(ws[:, li], noise_mode='const') for li in range(3)]
+    arrays['aio_imgs'] = torch.stack(imgs)
+    arrays['aio_logits'] = DA(imgs[1].detach())
+    cases.append(dict(id=7, op='aio_forward', S_kwargs=sk, D_kwargs=Dk, num_ws=S.num_ws))
+    save('nets', arrays, dict(cases=cases))
+
+
 if __name__ == '__main__':
     _import_reference()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv', 'montage']
+    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv', 'montage', 'nets']
     for w in which:
         globals()['gen_' + w]()
