@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the MontageGAN training hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload aio|single] [--batch-gpu B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one iteration of the training loop over one batch of synthetic, HBM-resident input: every phase
+whose interval divides the iteration index (Gmain/Dmain each step, Greg every 4th, Dreg every 16th -- per local
+GAN and for the global GAN), optimizer steps, EMA.  Default workload ``aio``: the full two-stage train_aio step,
+8 RGBA layers of 256x256, local StyleGAN2s + global placement GAN with the analytic alpha composite
+(``bypass_renderer``; the shipped renderer checkpoint is 9-layer only).  ``value`` = composed images
+per second over all ranks (weak scaling: the per-GPU batch is fixed).  Rank 0 prints ONE JSON line, with
+``roofline`` for the dominant hand-written kernel (HIP events on the launch stream, measured in this process)
+and ``cpu_baseline`` (the same loss/network code with the aten ``impl='ref'`` ops on the host cores, bounded sample).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = 'docker-montage-gan_amd'
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.3 TB/s achievable)
+
+
+def mod(name):
+    importlib.import_module(PKG)
+    return importlib.import_module(f'{PKG}.{name}')
+
+
+def build_trainer(args, device, rank, world):
+    dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.dtype]
+    nfp16 = 0 if args.dtype == 'fp32' else 4
+    if args.workload == 'aio':
+        TL = mod('custom.training_loop_aio')
+        DS = mod('custom.dataset_aio')
+        kw = TL.default_kwargs(num_gpus=world, batch_gpu=args.batch_gpu, num_fp16_res=nfp16, fp16_dtype=dtype)
+        kw.training_set_kwargs.num_layers = args.layers
+        kw.training_set_kwargs.resolution = args.res
+        if args.tiny:
+            for k in ('local_G_kwargs', 'local_D_kwargs', 'global_D_kwargs'):
+                kw[k].channel_base, kw[k].channel_max = 512, 32
+        cfg = dict(TL.config, bypass_renderer=True)
+        reals = [DS.synthetic_layers(args.batch_gpu, args.layers, args.res, seed=1000 * rank + i, device=device) for i in range(2)]
+        trainer = TL.AioTrainer(rank=rank, device=device, cfg=cfg, resident_batches=reals, random_seed=0, **kw)
+        name = (f'train_aio full step: {args.layers} local StyleGAN2 (G+D) + global GAN (STN + alpha composite + D), '
+                f'{args.res}x{args.res} RGBA, bypass_renderer, no ADA')
+    else:
+        TL = mod('training.training_loop')
+        kw = TL.default_kwargs(num_gpus=world, batch_gpu=args.batch_gpu, resolution=args.res, num_fp16_res=nfp16, fp16_dtype=dtype)
+        if args.tiny:
+            kw.G_kwargs.synthesis_kwargs.channel_base = kw.D_kwargs.channel_base = 512
+            kw.G_kwargs.synthesis_kwargs.channel_max = kw.D_kwargs.channel_max = 32
+        g = torch.Generator(device='cpu').manual_seed(rank)
+        reals = [(torch.randint(0, 256, [args.batch_gpu, 4, args.res, args.res], generator=g, dtype=torch.uint8).to(device),
+                  torch.zeros([args.batch_gpu, 0], device=device)) for _ in range(2)]
+        trainer = TL.Trainer(rank=rank, device=device, resident_batches=reals, random_seed=0, **kw)
+        name = f'train.py step: one StyleGAN2 G+D, {args.res}x{args.res} RGBA, no ADA'
+    return trainer, name
+
+
+def cpu_baseline(args):
+    """The same network/loss code on the host with the aten reference ops (impl='ref' because the tensors are
+    on the CPU): ONE local GAN's Gmain + Dmain phases at a small batch.  The full step also runs Greg/Dreg and,
+    for aio, the other L-1 local GANs and the global GAN; the sample is scaled by L only, so the reported CPU
+    rate is an UPPER bound."""
+    NW, LS = mod('training.networks'), mod('training.loss')
+    threads = int(os.environ.get('BENCH_CPU_THREADS', os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    b = args.cpu_batch
+    cci = 3 if args.workload == 'aio' else 2
+    init = [8, 8] if cci == 3 else [4, 4]
+    base = (512, 32) if args.tiny else (16384, 512)
+    S = NW.SynthesisNetwork(w_dim=512, img_resolution=args.res, img_channels=4, init_res=init, conv_config_index=cci,
+                            channel_base=base[0], channel_max=base[1], conv_clamp=256).train()
+    M = NW.MappingNetwork(z_dim=512, w_dim=512, num_ws=S.num_ws, num_layers=8 if cci == 3 else 2).train()
+    D = NW.Discriminator(img_resolution=args.res, img_channels=4, init_res=init, conv_config_index=cci, channel_base=base[0],
+                         channel_max=base[1], conv_clamp=256).train()
+    loss = LS.StyleGAN2Loss(device=torch.device('cpu'), G_mapping=M, G_synthesis=S, D=D)
+    real = torch.randn([b, 4, args.res, args.res])
+    c0 = torch.zeros([b, 0])
+
+    def one():
+        for phase, mods in (('Gmain', [M, S]), ('Dmain', [D])):
+            for m in mods:
+                m.requires_grad_(True)
+            loss.accumulate_gradients(phase=phase, real_img=real, gen_z=torch.randn([b, 512]), sync=True, gain=1, real_c=c0, gen_c=c0)
+            for m in mods:
+                m.requires_grad_(False)
+                for p in m.parameters():
+                    p.grad = None
+    one()                                   # warm-up
+    t0 = time.time()
+    reps = 0
+    while reps < 1 or (time.time() - t0 < args.cpu_seconds and reps < 8):
+        one()
+        reps += 1
+    dt = (time.time() - t0) / reps
+    layers = args.layers if args.workload == 'aio' else 1
+    return dict(value=round(b / (dt * layers), 4), unit='img/s', cores=threads, kind='port',
+                sample=(f'1 local GAN, phases Gmain+Dmain only, batch {b}, {args.res}x{args.res} fp32, {reps} repetition(s) of '
+                        f'{dt:.1f} s, scaled by {layers} layer(s); Greg/Dreg/global phases not run => upper bound of the CPU rate'))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=16)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='aio', choices=['aio', 'single'])
+    ap.add_argument('--batch-gpu', type=int, default=None)
+    ap.add_argument('--layers', type=int, default=8)
+    ap.add_argument('--res', type=int, default=256)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--tiny', action='store_true', help='small channel counts (smoke runs only; the line is marked)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--prof-steps', type=int, default=4, help='extra (untimed) steps with per-kernel HIP events for the roofline object')
+    ap.add_argument('--no-stats', action='store_true', help='turn training_stats.report into a no-op')
+    args = ap.parse_args()
+    if args.batch_gpu is None:
+        args.batch_gpu = 8 if args.workload == 'aio' else 32
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.distributed.init_process_group(backend='nccl', device_id=device)        # nccl == RCCL on ROCm
+
+    native = mod('torch_utils.native')
+    native.lib()                                # fail loudly if the HIP library is missing
+    if args.no_stats:
+        mod('torch_utils.training_stats').enabled = False
+    mod('torch_utils.custom_ops').verbosity = 'none'
+
+    trainer, workload = build_trainer(args, device, rank, world)
+
+    def sync_all():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        trainer.run_iteration()
+    sync_all()
+    counts0 = native.launch_counts()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.run_iteration()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    counts1 = native.launch_counts()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel timing of the hand-written kernels (extra steps, outside the timed region)
+    roofline = None
+    if rank == 0 and args.prof_steps > 0:
+        native.prof_reset()
+        native.prof_enable(True)
+        for _ in range(args.prof_steps):
+            trainer.run_iteration()
+        torch.cuda.synchronize(device)
+        rec = native.prof_collect()
+        native.prof_enable(False)
+        native.prof_reset()
+        if rec:
+            total_ms = sum(v['ms'] for v in rec.values())
+            name, top = max(rec.items(), key=lambda kv: kv[1]['ms'])
+            achieved = top['bytes'] / (top['ms'] * 1e-3) / 1e9
+            roofline = dict(bound='hbm', kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
+                            frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=None,
+                            launches_per_step=round(top['launches'] / args.prof_steps, 1),
+                            avg_launch_us=round(top['ms'] * 1e3 / top['launches'], 2),
+                            algorithmic_bytes_per_launch=round(top['bytes'] / top['launches']),
+                            all_kernels={k: dict(ms_per_step=round(v['ms'] / args.prof_steps, 3), launches_per_step=round(v['launches'] / args.prof_steps, 1),
+                                                 GBps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1)) for k, v in rec.items()},
+                            native_ms_per_step=round(total_ms / args.prof_steps, 3))
+    elif world > 1:
+        for _ in range(0):
+            pass
+
+    if rank == 0:
+        imgs = args.batch_gpu * world * args.steps
+        out = {
+            'metric': 'img/sec (full G+D step), 8-layer 256^2 RGBA' if args.workload == 'aio' else 'img/sec (full G+D step), single StyleGAN2 256^2 RGBA',
+            'value': round(imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': workload + (' [TINY channel counts: smoke only]' if args.tiny else ''), 'global_batch': args.batch_gpu * world,
+                       'batch_per_gpu': args.batch_gpu, 'layers': args.layers if args.workload == 'aio' else 1, 'resolution': args.res,
+                       'parallelism': f'dp{world} (one flat-buffer RCCL all-reduce per phase)',
+                       'native_launches_per_step': {k: round((counts1[k] - counts0[k]) / args.steps, 1) for k in counts1 if counts1[k] - counts0[k]}},
+            'roofline': roofline,
+            'cpu_baseline': None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,134 @@
+"""The callers on the GPU: networks, loss phases and one full (tiny) training iteration with the native
+ops, against (a) the reference's golden values and (b) the same code with every op forced to its aten
+`impl='ref'` path on the same device and RNG stream.  Need a real MI355X."""
+import functools
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, load_pkg
+from test_nets_golden import build_gd, T, mod
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def force_ref(monkeypatch):
+    """Route every plugin op to its aten composition (explicit impl='ref'), fused epilogue off."""
+    U, B = mod('torch_utils.ops.upfirdn2d'), mod('torch_utils.ops.bias_act')
+    A, TS = mod('torch_utils.ops.alpha_composite'), mod('torch_utils.ops.translate_sample')
+    NW = mod('training.networks')
+    real_up = U.upfirdn2d
+
+    def up_ref(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cuda'):
+        return real_up(x, f, up=up, down=down, padding=padding, flip_filter=flip_filter, gain=gain, impl='ref')
+    monkeypatch.setattr(U, 'upfirdn2d', up_ref)
+    real_ba = B.bias_act
+
+    def ba_ref(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, impl='cuda'):
+        return real_ba(x, b, dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp, impl='ref')
+    monkeypatch.setattr(B, 'bias_act', ba_ref)
+    monkeypatch.setattr(A, 'alpha_composite', functools.partial(A.alpha_composite, impl='ref'))
+    monkeypatch.setattr(TS, 'translate_sample', functools.partial(TS.translate_sample, impl='ref'))
+    monkeypatch.setattr(NW, 'fused_epilogue', False)
+
+
+def test_forward_matches_reference_golden_on_gpu():
+    native = load_pkg().native
+    cases, arr = load_golden('nets')
+    G, D = build_gd(arr, cases, device=DEV)
+    z = T(arr['z']).to(DEV)
+    G.train(); D.train()
+    before = native.launch_counts()
+    img = G(z, noise_mode='const')
+    logits = D(img.detach())
+    after = native.launch_counts()
+    assert after['bias_act'] > before['bias_act'] and after['upfirdn2d_tiled'] + after['upfirdn2d_generic'] > \
+        before['upfirdn2d_tiled'] + before['upfirdn2d_generic'] and after['fma_bias_act'] > before['fma_bias_act']
+    np.testing.assert_allclose(img.detach().cpu().numpy(), arr['img_train'], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), arr['logits'], rtol=1e-3, atol=1e-3)
+    G.eval()
+    np.testing.assert_allclose(G(z, noise_mode='const').detach().cpu().numpy(), arr['img_eval'], rtol=1e-3, atol=1e-3)
+
+
+def _phase_grads(phase, arr, cases, seed):
+    LS = mod('training.loss')
+    G, D = build_gd(arr, cases, device=DEV)
+    G.train(); D.train()
+    G.requires_grad_(phase[0] == 'G'); D.requires_grad_(phase[0] == 'D')
+    loss = LS.StyleGAN2Loss(device=torch.device(DEV), G_mapping=G.mapping, G_synthesis=G.synthesis, D=D)
+    torch.manual_seed(seed)
+    gen_z = torch.randn([4, 32], device=DEV)
+    c0 = torch.zeros([4, 0], device=DEV)
+    loss.accumulate_gradients(phase=phase, real_img=T(arr['real']).to(DEV), gen_z=gen_z, sync=True, gain=1.0, real_c=c0, gen_c=c0)
+    m = G if phase[0] == 'G' else D
+    return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize('phase', ['Gmain', 'Greg', 'Dmain', 'Dreg'])
+def test_loss_phase_native_equals_aten_ref_on_gpu(phase, monkeypatch):
+    """Same device, same RNG stream: native kernels (incl. fused epilogue and the double-backward paths of
+    R1 / path length) vs the aten compositions."""
+    cases, arr = load_golden('nets')
+    G_ = mod('torch_utils.ops.conv2d_gradfix')
+    G_.enabled = True
+    try:
+        got = _phase_grads(phase, arr, cases, seed=77)
+        with monkeypatch.context() as mp:
+            force_ref(mp)
+            want = _phase_grads(phase, arr, cases, seed=77)
+    finally:
+        G_.enabled = False
+    assert got.keys() == want.keys() and len(got) > 10
+    for n in got:
+        scale = max(1e-3, float(want[n].abs().max()))
+        err = float((got[n] - want[n]).abs().max()) / scale
+        assert err < 2e-3, f'{phase} {n}: rel err {err:.2e}'
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_mixed_precision_step_is_finite_and_close(dtype):
+    NW = mod('training.networks')
+    torch.manual_seed(0)
+    kw = dict(w_dim=64, img_resolution=64, img_channels=4, channel_base=1024, channel_max=64, conv_clamp=256)
+    S32 = NW.SynthesisNetwork(num_fp16_res=0, **kw).to(DEV).train()
+    S16 = NW.SynthesisNetwork(num_fp16_res=3, fp16_dtype=dtype, **kw).to(DEV).train()
+    S16.load_state_dict(S32.state_dict())
+    ws = torch.randn([4, S32.num_ws, 64], device=DEV)
+    a, b = S32(ws, noise_mode='const'), S16(ws, noise_mode='const')
+    assert torch.isfinite(b).all() and b.dtype == torch.float32
+    rel = float((a - b).abs().mean() / a.abs().mean())
+    assert rel < (0.02 if dtype == torch.float16 else 0.08), rel
+    b.square().mean().backward()
+    assert all(torch.isfinite(p.grad).all() for p in S16.parameters() if p.grad is not None)
+
+
+def test_aio_iteration_runs_native_and_updates_weights():
+    """One full (tiny) train_aio iteration on the GPU: every phase fires at batch_idx 0; the native kernels
+    run; weights move; a second iteration skips the lazy-regularisation phases."""
+    native = load_pkg().native
+    TL, DS = mod('custom.training_loop_aio'), mod('custom.dataset_aio')
+    kw = TL.default_kwargs(num_gpus=1, batch_gpu=2, num_fp16_res=2, fp16_dtype=torch.bfloat16)
+    for k in ('local_G_kwargs', 'local_D_kwargs', 'global_D_kwargs'):
+        kw[k].channel_base, kw[k].channel_max = 256, 16
+    kw.mapping_kwargs.num_layers = 2
+    kw.training_set_kwargs.num_layers = 3
+    reals = [DS.synthetic_layers(2, 3, 256, seed=5, device=DEV)]
+    t = TL.AioTrainer(device=DEV, cfg=dict(TL.config, bypass_renderer=True), resident_batches=reals, **kw)
+    w0 = [p.detach().clone() for p in t.local_G_list[0].parameters()][:3]
+    stn0 = t.pos_estimator.fc_loc[2].bias.detach().clone()
+    before = native.launch_counts()
+    assert t.run_iteration() == 16          # 3 x (Gmain, Greg, Dmain, Dreg) + global x 4
+    after = native.launch_counts()
+    for k in ('bias_act', 'fma_bias_act', 'alpha_composite_fwd', 'alpha_composite_bwd', 'translate_fwd', 'translate_bwd_input',
+              'translate_bwd_shift'):
+        assert after[k] > before[k], k
+    assert after['upfirdn2d_tiled'] > before['upfirdn2d_tiled']
+    assert t.run_iteration() == 8           # only the main phases at batch_idx 1
+    torch.cuda.synchronize()
+    w1 = [p.detach() for p in t.local_G_list[0].parameters()][:3]
+    assert any(not torch.equal(a, b) for a, b in zip(w0, w1))
+    assert all(torch.isfinite(p).all() for g in t.local_G_list for p in g.parameters())
+    assert not torch.equal(stn0, t.pos_estimator.fc_loc[2].bias.detach())       # the STN learns a placement
