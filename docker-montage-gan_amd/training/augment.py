@@ -1,0 +1,317 @@
+"""Adaptive discriminator augmentation pipeline (ADA).
+
+Same class, constructor arguments, buffers (``p``, ``Hz_geom``, ``Hz_fbank``) and -- deliberately -- the same
+ORDER and SHAPES of random draws as the reference's ``training/augment.py`` (AugmentPipe :156-482, with the
+RGBA branch of the colour stage :403-406), so that a seeded CPU run reproduces its output and
+``debug_percentile`` gives the same deterministic images.
+
+It is the main consumer of the separable resampler: the geometric stage is
+``pad(reflect) -> upfirdn2d.upsample2d(sym6, x2) -> grid_sample_gradfix.grid_sample -> upfirdn2d.downsample2d(sym6, /2)``
+i.e. four launches of csrc/upfirdn2d.hip (two separable passes each) around aten's sampler.
+Host-sync note: the reflect-padding margin is data dependent and read back as python ints (one sync per
+call, as upstream :313); removing it means a fused pad+sample kernel -- SURVEY 8(f) rank 1, not done yet.
+"""
+import numpy as np
+import scipy.signal
+import torch
+
+from ..torch_utils import misc
+from ..torch_utils.ops import conv2d_gradfix
+from ..torch_utils.ops import grid_sample_gradfix
+from ..torch_utils.ops import upfirdn2d
+
+# Orthogonal wavelet low-pass filters (Daubechies / symlets), as tabulated in PyWavelets.
+wavelets = {
+    'haar': [0.7071067811865476, 0.7071067811865476],
+    'db1': [0.7071067811865476, 0.7071067811865476],
+    'db2': [-0.12940952255092145, 0.22414386804185735, 0.836516303737469, 0.48296291314469025],
+    'db3': [0.035226291882100656, -0.08544127388224149, -0.13501102001039084, 0.4598775021193313, 0.8068915093133388, 0.3326705529509569],
+    'db4': [-0.010597401784997278, 0.032883011666982945, 0.030841381835986965, -0.18703481171888114, -0.02798376941698385,
+            0.6308807679295904, 0.7148465705525415, 0.23037781330885523],
+    'sym2': [-0.12940952255092145, 0.22414386804185735, 0.836516303737469, 0.48296291314469025],
+    'sym3': [0.035226291882100656, -0.08544127388224149, -0.13501102001039084, 0.4598775021193313, 0.8068915093133388, 0.3326705529509569],
+    'sym4': [-0.07576571478927333, -0.02963552764599851, 0.49761866763201545, 0.8037387518059161, 0.29785779560527736,
+             -0.09921954357684722, -0.012603967262037833, 0.0322231006040427],
+    'sym5': [0.027333068345077982, 0.029519490925774643, -0.039134249302383094, 0.1993975339773936, 0.7234076904024206,
+             0.6339789634582119, 0.01660210576452232, -0.17532808990845047, -0.021101834024758855, 0.019538882735286728],
+    'sym6': [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.048311742585633, 0.4910559419267466,
+             0.787641141030194, 0.3379294217276218, -0.07263752278646252, -0.021060292512300564, 0.04472490177066578,
+             0.0017677118642428036, -0.007800708325034148],
+}
+
+
+def matrix(*rows, device=None):
+    """Rows of python scalars and/or batched tensors -> [..., R, C] (constants broadcast to the batch shape)."""
+    assert all(len(row) == len(rows[0]) for row in rows)
+    elems = [x for row in rows for x in row]
+    ref = [x for x in elems if isinstance(x, torch.Tensor)]
+    if not ref:
+        return misc.constant(np.asarray(rows), device=device)
+    assert device is None or device == ref[0].device
+    elems = [x if isinstance(x, torch.Tensor) else misc.constant(x, shape=ref[0].shape, device=ref[0].device) for x in elems]
+    return torch.stack(elems, dim=-1).reshape(ref[0].shape + (len(rows), -1))
+
+
+def translate2d(tx, ty, **kw):
+    return matrix([1, 0, tx], [0, 1, ty], [0, 0, 1], **kw)
+
+
+def translate3d(tx, ty, tz, **kw):
+    return matrix([1, 0, 0, tx], [0, 1, 0, ty], [0, 0, 1, tz], [0, 0, 0, 1], **kw)
+
+
+def scale2d(sx, sy, **kw):
+    return matrix([sx, 0, 0], [0, sy, 0], [0, 0, 1], **kw)
+
+
+def scale3d(sx, sy, sz, **kw):
+    return matrix([sx, 0, 0, 0], [0, sy, 0, 0], [0, 0, sz, 0], [0, 0, 0, 1], **kw)
+
+
+def rotate2d(theta, **kw):
+    return matrix([torch.cos(theta), torch.sin(-theta), 0], [torch.sin(theta), torch.cos(theta), 0], [0, 0, 1], **kw)
+
+
+def rotate3d(v, theta, **kw):
+    vx, vy, vz = v[..., 0], v[..., 1], v[..., 2]
+    s, c = torch.sin(theta), torch.cos(theta)
+    cc = 1 - c
+    return matrix([vx * vx * cc + c, vx * vy * cc - vz * s, vx * vz * cc + vy * s, 0],
+                  [vy * vx * cc + vz * s, vy * vy * cc + c, vy * vz * cc - vx * s, 0],
+                  [vz * vx * cc - vy * s, vz * vy * cc + vx * s, vz * vz * cc + c, 0],
+                  [0, 0, 0, 1], **kw)
+
+
+def translate2d_inv(tx, ty, **kw):
+    return translate2d(-tx, -ty, **kw)
+
+
+def scale2d_inv(sx, sy, **kw):
+    return scale2d(1 / sx, 1 / sy, **kw)
+
+
+def rotate2d_inv(theta, **kw):
+    return rotate2d(-theta, **kw)
+
+
+class AugmentPipe(torch.nn.Module):
+    def __init__(self, xflip=0, rotate90=0, xint=0, xint_max=0.125, scale=0, rotate=0, aniso=0, xfrac=0, scale_std=0.2,
+                 rotate_max=1, aniso_std=0.2, xfrac_std=0.125, brightness=0, contrast=0, lumaflip=0, hue=0, saturation=0,
+                 brightness_std=0.2, contrast_std=0.5, hue_max=1, saturation_std=1, imgfilter=0, imgfilter_bands=[1, 1, 1, 1],
+                 imgfilter_std=1, noise=0, cutout=0, noise_std=0.1, cutout_size=0.5):
+        super().__init__()
+        self.register_buffer('p', torch.ones([]))       # overall multiplier of every probability below
+        for k, v in dict(xflip=xflip, rotate90=rotate90, xint=xint, xint_max=xint_max, scale=scale, rotate=rotate, aniso=aniso,
+                         xfrac=xfrac, scale_std=scale_std, rotate_max=rotate_max, aniso_std=aniso_std, xfrac_std=xfrac_std,
+                         brightness=brightness, contrast=contrast, lumaflip=lumaflip, hue=hue, saturation=saturation,
+                         brightness_std=brightness_std, contrast_std=contrast_std, hue_max=hue_max,
+                         saturation_std=saturation_std, imgfilter=imgfilter, imgfilter_std=imgfilter_std, noise=noise,
+                         cutout=cutout, noise_std=noise_std, cutout_size=cutout_size).items():
+            setattr(self, k, float(v))
+        self.imgfilter_bands = list(imgfilter_bands)
+        self.register_buffer('Hz_geom', upfirdn2d.setup_filter(wavelets['sym6']))       # 12 taps -> separable
+        # 4-band filter bank from sym2 for the image-space filter stage (:197-207)
+        lo = np.asarray(wavelets['sym2'])
+        hi = lo * ((-1) ** np.arange(lo.size))
+        lo2, hi2 = np.convolve(lo, lo[::-1]) / 2, np.convolve(hi, hi[::-1]) / 2
+        fbank = np.eye(4, 1)
+        for i in range(1, fbank.shape[0]):
+            fbank = np.dstack([fbank, np.zeros_like(fbank)]).reshape(fbank.shape[0], -1)[:, :-1]
+            fbank = scipy.signal.convolve(fbank, [lo2])
+            fbank[i, (fbank.shape[1] - hi2.size) // 2:(fbank.shape[1] + hi2.size) // 2] += hi2
+        self.register_buffer('Hz_fbank', torch.as_tensor(fbank, dtype=torch.float32))
+
+    # one "maybe apply" draw: value where rand < prob else neutral; debug_percentile overrides both draws
+    @staticmethod
+    def _gate(value, prob, neutral, shape, device):
+        return torch.where(torch.rand(shape, device=device) < prob, value, neutral)
+
+    def forward(self, images, debug_percentile=None):
+        assert isinstance(images, torch.Tensor) and images.ndim == 4
+        n, ch, height, width = images.shape
+        dev = images.device
+        dp = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32, device=dev)
+        rand, randn = (lambda *s: torch.rand(list(s), device=dev)), (lambda *s: torch.randn(list(s), device=dev))
+
+        # ---- pixel blitting + general geometric transforms, accumulated as one inverse matrix ----
+        I_3 = torch.eye(3, device=dev)
+        G_inv = I_3
+        if self.xflip > 0:
+            i = torch.floor(rand(n) * 2)
+            i = self._gate(i, self.xflip * self.p, torch.zeros_like(i), [n], dev)
+            if dp is not None:
+                i = torch.full_like(i, torch.floor(dp * 2))
+            G_inv = G_inv @ scale2d_inv(1 - 2 * i, 1)
+        if self.rotate90 > 0:
+            i = torch.floor(rand(n) * 4)
+            i = self._gate(i, self.rotate90 * self.p, torch.zeros_like(i), [n], dev)
+            if dp is not None:
+                i = torch.full_like(i, torch.floor(dp * 4))
+            G_inv = G_inv @ rotate2d_inv(-np.pi / 2 * i)
+        if self.xint > 0:
+            t = (rand(n, 2) * 2 - 1) * self.xint_max
+            t = self._gate(t, self.xint * self.p, torch.zeros_like(t), [n, 1], dev)
+            if dp is not None:
+                t = torch.full_like(t, (dp * 2 - 1) * self.xint_max)
+            G_inv = G_inv @ translate2d_inv(torch.round(t[:, 0] * width), torch.round(t[:, 1] * height))
+        if self.scale > 0:
+            s = torch.exp2(randn(n) * self.scale_std)
+            s = self._gate(s, self.scale * self.p, torch.ones_like(s), [n], dev)
+            if dp is not None:
+                s = torch.full_like(s, torch.exp2(torch.erfinv(dp * 2 - 1) * self.scale_std))
+            G_inv = G_inv @ scale2d_inv(s, s)
+        p_rot = 1 - torch.sqrt((1 - self.rotate * self.p).clamp(0, 1))      # P(pre OR post rotation) = p
+        if self.rotate > 0:
+            theta = (rand(n) * 2 - 1) * np.pi * self.rotate_max
+            theta = self._gate(theta, p_rot, torch.zeros_like(theta), [n], dev)
+            if dp is not None:
+                theta = torch.full_like(theta, (dp * 2 - 1) * np.pi * self.rotate_max)
+            G_inv = G_inv @ rotate2d_inv(-theta)
+        if self.aniso > 0:
+            s = torch.exp2(randn(n) * self.aniso_std)
+            s = self._gate(s, self.aniso * self.p, torch.ones_like(s), [n], dev)
+            if dp is not None:
+                s = torch.full_like(s, torch.exp2(torch.erfinv(dp * 2 - 1) * self.aniso_std))
+            G_inv = G_inv @ scale2d_inv(s, 1 / s)
+        if self.rotate > 0:
+            theta = (rand(n) * 2 - 1) * np.pi * self.rotate_max
+            theta = self._gate(theta, p_rot, torch.zeros_like(theta), [n], dev)
+            if dp is not None:
+                theta = torch.zeros_like(theta)
+            G_inv = G_inv @ rotate2d_inv(-theta)
+        if self.xfrac > 0:
+            t = randn(n, 2) * self.xfrac_std
+            t = self._gate(t, self.xfrac * self.p, torch.zeros_like(t), [n, 1], dev)
+            if dp is not None:
+                t = torch.full_like(t, torch.erfinv(dp * 2 - 1) * self.xfrac_std)
+            G_inv = G_inv @ translate2d_inv(t[:, 0] * width, t[:, 1] * height)
+
+        if G_inv is not I_3:
+            # how far do the transformed image corners reach?  -> reflect padding needed
+            cx, cy = (width - 1) / 2, (height - 1) / 2
+            corners = matrix([-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1], device=dev)
+            corners = G_inv @ corners.t()                                       # [batch, xyz, corner]
+            hz_pad = self.Hz_geom.shape[0] // 4
+            margin = corners[:, :2, :].permute(1, 0, 2).flatten(1)              # [xy, batch*corner]
+            margin = torch.cat([-margin, margin]).max(dim=1).values             # [x0, y0, x1, y1]
+            margin = margin + misc.constant([hz_pad * 2 - cx, hz_pad * 2 - cy] * 2, device=dev)
+            margin = margin.max(misc.constant([0, 0] * 2, device=dev)).min(misc.constant([width - 1, height - 1] * 2, device=dev))
+            mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().to(torch.int32).tolist())       # the one host sync
+            images = torch.nn.functional.pad(input=images, pad=[mx0, mx1, my0, my1], mode='reflect')
+            G_inv = translate2d((mx0 - mx1) / 2, (my0 - my1) / 2, device=dev) @ G_inv
+            # x2 upsample with the 12-tap symlet (separable -> two native passes)
+            images = upfirdn2d.upsample2d(x=images, f=self.Hz_geom, up=2)
+            G_inv = scale2d(2, 2, device=dev) @ G_inv @ scale2d_inv(2, 2, device=dev)
+            G_inv = translate2d(-0.5, -0.5, device=dev) @ G_inv @ translate2d_inv(-0.5, -0.5, device=dev)
+            # sample on the output lattice
+            shape = [n, ch, (height + hz_pad * 2) * 2, (width + hz_pad * 2) * 2]
+            G_inv = scale2d(2 / images.shape[3], 2 / images.shape[2], device=dev) @ G_inv @ scale2d_inv(2 / shape[3], 2 / shape[2], device=dev)
+            grid = torch.nn.functional.affine_grid(theta=G_inv[:, :2, :], size=shape, align_corners=False)
+            images = grid_sample_gradfix.grid_sample(images, grid)
+            # back down, cropping the filter margin
+            images = upfirdn2d.downsample2d(x=images, f=self.Hz_geom, down=2, padding=-hz_pad * 2, flip_filter=True)
+
+        # ---- colour transforms, accumulated as one 4x4 matrix on (r, g, b, 1) ----
+        I_4 = torch.eye(4, device=dev)
+        C = I_4
+        if self.brightness > 0:
+            b = randn(n) * self.brightness_std
+            b = self._gate(b, self.brightness * self.p, torch.zeros_like(b), [n], dev)
+            if dp is not None:
+                b = torch.full_like(b, torch.erfinv(dp * 2 - 1) * self.brightness_std)
+            C = translate3d(b, b, b) @ C
+        if self.contrast > 0:
+            c = torch.exp2(randn(n) * self.contrast_std)
+            c = self._gate(c, self.contrast * self.p, torch.ones_like(c), [n], dev)
+            if dp is not None:
+                c = torch.full_like(c, torch.exp2(torch.erfinv(dp * 2 - 1) * self.contrast_std))
+            C = scale3d(c, c, c) @ C
+        v = misc.constant(np.asarray([1, 1, 1, 0]) / np.sqrt(3), device=dev)       # luma axis
+        vv = torch.outer(v, v)
+        if self.lumaflip > 0:
+            i = torch.floor(rand(n, 1, 1) * 2)
+            i = self._gate(i, self.lumaflip * self.p, torch.zeros_like(i), [n, 1, 1], dev)
+            if dp is not None:
+                i = torch.full_like(i, torch.floor(dp * 2))
+            C = (I_4 - 2 * vv * i) @ C                                             # Householder reflection
+        if self.hue > 0 and ch > 1:
+            theta = (rand(n) * 2 - 1) * np.pi * self.hue_max
+            theta = self._gate(theta, self.hue * self.p, torch.zeros_like(theta), [n], dev)
+            if dp is not None:
+                theta = torch.full_like(theta, (dp * 2 - 1) * np.pi * self.hue_max)
+            C = rotate3d(v, theta) @ C
+        if self.saturation > 0 and ch > 1:
+            s = torch.exp2(randn(n, 1, 1) * self.saturation_std)
+            s = self._gate(s, self.saturation * self.p, torch.ones_like(s), [n, 1, 1], dev)
+            if dp is not None:
+                s = torch.full_like(s, torch.exp2(torch.erfinv(dp * 2 - 1) * self.saturation_std))
+            C = (vv + (I_4 - vv) * s) @ C
+        if C is not I_4:
+            flat = images.reshape([n, ch, height * width])
+            if ch == 4:         # RGBA: colour matrix on RGB, alpha untouched (reference :403-406)
+                flat = torch.cat([C[:, :3, :3] @ flat[:, :3, :] + C[:, :3, 3:], flat[:, 3:, :]], dim=1)
+            elif ch == 3:
+                flat = C[:, :3, :3] @ flat + C[:, :3, 3:]
+            elif ch == 1:
+                Cm = C[:, :3, :].mean(dim=1, keepdims=True)
+                flat = flat * Cm[:, :, :3].sum(dim=2, keepdims=True) + Cm[:, :, 3:]
+            else:
+                raise ValueError('Image must be RGBA (4 channels), RGB (3 channels) or L (1 channel)')
+            images = flat.reshape([n, ch, height, width])
+
+        # ---- image-space filtering ----
+        if self.imgfilter > 0:
+            bands = self.Hz_fbank.shape[0]
+            assert len(self.imgfilter_bands) == bands
+            expected_power = misc.constant(np.array([10, 1, 1, 1]) / 13, device=dev)       # 1/f spectrum
+            g = torch.ones([n, bands], device=dev)
+            for i, strength in enumerate(self.imgfilter_bands):
+                t_i = torch.exp2(randn(n) * self.imgfilter_std)
+                t_i = self._gate(t_i, self.imgfilter * self.p * strength, torch.ones_like(t_i), [n], dev)
+                if dp is not None:
+                    t_i = torch.full_like(t_i, torch.exp2(torch.erfinv(dp * 2 - 1) * self.imgfilter_std)) if strength > 0 else torch.ones_like(t_i)
+                t = torch.ones([n, bands], device=dev)
+                t[:, i] = t_i
+                t = t / (expected_power * t.square()).sum(dim=-1, keepdims=True).sqrt()
+                g = g * t
+            taps = (g @ self.Hz_fbank).unsqueeze(1).repeat([1, ch, 1]).reshape([n * ch, 1, -1])
+            pad = self.Hz_fbank.shape[1] // 2
+            images = images.reshape([1, n * ch, height, width])
+            images = torch.nn.functional.pad(input=images, pad=[pad, pad, pad, pad], mode='reflect')
+            images = conv2d_gradfix.conv2d(input=images, weight=taps.unsqueeze(2), groups=n * ch)
+            images = conv2d_gradfix.conv2d(input=images, weight=taps.unsqueeze(3), groups=n * ch)
+            images = images.reshape([n, ch, height, width])
+
+        # ---- image-space corruptions ----
+        if self.noise > 0:
+            sigma = randn(n, 1, 1, 1).abs() * self.noise_std
+            sigma = self._gate(sigma, self.noise * self.p, torch.zeros_like(sigma), [n, 1, 1, 1], dev)
+            if dp is not None:
+                sigma = torch.full_like(sigma, torch.erfinv(dp) * self.noise_std)
+            images = images + randn(n, ch, height, width) * sigma
+        if self.cutout > 0:
+            size = torch.full([n, 2, 1, 1, 1], self.cutout_size, device=dev)
+            size = self._gate(size, self.cutout * self.p, torch.zeros_like(size), [n, 1, 1, 1, 1], dev)
+            center = rand(n, 2, 1, 1, 1)
+            if dp is not None:
+                size = torch.full_like(size, self.cutout_size)
+                center = torch.full_like(center, dp)
+            cx_ = torch.arange(width, device=dev).reshape([1, 1, 1, -1])
+            cy_ = torch.arange(height, device=dev).reshape([1, 1, -1, 1])
+            mask_x = ((cx_ + 0.5) / width - center[:, 0]).abs() >= size[:, 0] / 2
+            mask_y = ((cy_ + 0.5) / height - center[:, 1]).abs() >= size[:, 1] / 2
+            images = images * torch.logical_or(mask_x, mask_y).to(torch.float32)
+        return images
+
+
+augpipe_specs = {       # train.py:245-259 / train_aio.py augpipe table
+    'blit': dict(xflip=1, rotate90=1, xint=1),
+    'geom': dict(scale=1, rotate=1, aniso=1, xfrac=1),
+    'color': dict(brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1),
+    'filter': dict(imgfilter=1),
+    'noise': dict(noise=1),
+    'cutout': dict(cutout=1),
+    'bg': dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1),
+    'bgc': dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1,
+                saturation=1),
+}

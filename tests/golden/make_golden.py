@@ -396,9 +396,59 @@ def gen_nets():
     save('nets', arrays, dict(cases=cases))
 
 
+# ----------------------------------------------------------------------------
+def gen_augment():
+    """AugmentPipe (training/augment.py:156-482): deterministic debug_percentile outputs and seeded random
+    outputs, RGBA and RGB; plus the layout glue of the aio loop (image_utils.py:198-291)."""
+    from training import augment as AU
+    from custom_utils import image_utils as IU
+    g = torch.Generator().manual_seed(31)
+    arrays, cases = {}, []
+    bgc = dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1)
+    allaug = dict(bgc, imgfilter=1, noise=1, cutout=1)
+    x4 = torch.rand([3, 4, 32, 32], generator=g) * 2 - 1
+    x3 = torch.rand([2, 3, 24, 40], generator=g) * 2 - 1
+    arrays['x4'], arrays['x3'] = x4, x3
+    i = 0
+    for name, spec, x in (('bgc', bgc, 'x4'), ('all', allaug, 'x4'), ('bgc', bgc, 'x3')):
+        pipe = AU.AugmentPipe(**spec)
+        for pct in (0.1, 0.5, 0.9):
+            arrays[f'c{i}_y'] = pipe(arrays[x].clone(), debug_percentile=pct)
+            cases.append(dict(id=i, op='augment', spec=name, x=x, debug_percentile=pct, seed=None, p=1.0)); i += 1
+        for pval, seed in ((0.3, 5), (1.0, 6)):
+            pipe.p.copy_(torch.as_tensor(pval))
+            torch.manual_seed(seed)
+            xr = arrays[x].clone().requires_grad_(True)
+            y = pipe(xr)
+            dy = torch.randn(y.shape, generator=g)
+            arrays[f'c{i}_y'], arrays[f'c{i}_dy'] = y, dy
+            arrays[f'c{i}_dx'], = torch.autograd.grad([y], [xr], [dy])
+            cases.append(dict(id=i, op='augment', spec=name, x=x, debug_percentile=None, seed=seed, p=pval)); i += 1
+
+    # layout glue: content boxes / centring of real layers
+    lay = torch.zeros([2, 3, 4, 256, 256])
+    boxes = [(40, 60, 100, 90), (0, 0, 255, 255), (10, 200, 50, 256), (128, 128, 129, 129), None, (5, 5, 250, 7)]
+    for k, bx in enumerate(boxes):
+        b_, l_ = divmod(k, 3)
+        if bx is None:
+            continue
+        x1, y1, x2, y2 = bx
+        lay[b_, l_, :, y1:y2, x1:x2] = torch.rand([4, y2 - y1, x2 - x1], generator=g) * 0.9 + 0.1
+    arrays['lay'] = (lay * 255).round().to(torch.uint8)
+    lay = arrays['lay'].float() / 255
+    pf = IU.generate_pseudo_fake(lay)
+    arrays['pseudo_fake_u8'] = (pf * 255).round().to(torch.uint8)
+    sizes = [[256, 256], [128, 64], [32, 256]]
+    outs = IU.make_batch_for_local_d(lay, sizes, to_minus11=True)
+    for k, o in enumerate(outs):
+        arrays[f'local_d_{k}'] = o
+    cases.append(dict(id=i, op='layout', sizes=sizes))
+    save('augment', arrays, dict(cases=cases))
+
+
 if __name__ == '__main__':
     _import_reference()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv', 'montage', 'nets']
+    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv', 'montage', 'nets', 'augment']
     for w in which:
         globals()['gen_' + w]()

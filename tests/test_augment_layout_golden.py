@@ -1,0 +1,76 @@
+"""AugmentPipe and the aio layout glue against the reference's outputs (tests/golden/augment.*):
+deterministic debug_percentile images, seeded random images + input gradients, pseudo-fake centring
+and per-layer crops.  CPU only (the GPU variant reuses these helpers)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, load_pkg
+
+PKG = 'docker-montage-gan_amd'
+SPECS = None
+
+
+def mod(name):
+    load_pkg()
+    return importlib.import_module(f'{PKG}.{name}')
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def run_augment_case(c, arr, device='cpu'):
+    AU = mod('training.augment')
+    spec = dict(AU.augpipe_specs['bgc'])
+    if c['spec'] == 'all':
+        spec.update(imgfilter=1, noise=1, cutout=1)
+    pipe = AU.AugmentPipe(**spec).to(device)
+    pipe.p.copy_(torch.as_tensor(c['p']))
+    x = T(arr[c['x']]).to(device)
+    if c['debug_percentile'] is not None:
+        return pipe(x.clone(), debug_percentile=c['debug_percentile']), None
+    torch.manual_seed(c['seed'])
+    xr = x.clone().requires_grad_(True)
+    y = pipe(xr)
+    dx, = torch.autograd.grad([y], [xr], [T(arr[f'c{c["id"]}_dy']).to(device)])
+    return y, dx
+
+
+def test_augment_pipe_matches_reference():
+    cases, arr = load_golden('augment')
+    GS = mod('torch_utils.ops.grid_sample_gradfix')
+    n = 0
+    for enabled in (False, True):
+        GS.enabled = enabled
+        try:
+            for c in cases:
+                if c['op'] != 'augment':
+                    continue
+                y, dx = run_augment_case(c, arr)
+                np.testing.assert_allclose(y.detach().numpy(), arr[f'c{c["id"]}_y'], rtol=1e-4, atol=2e-5, err_msg=str(c))
+                if dx is not None:
+                    np.testing.assert_allclose(dx.numpy(), arr[f'c{c["id"]}_dx'], rtol=1e-4, atol=2e-5, err_msg=str(c))
+                n += 1
+        finally:
+            GS.enabled = False
+    assert n == 30
+
+
+def test_layout_glue_matches_reference():
+    IU = mod('custom_utils.image_utils')
+    cases, arr = load_golden('augment')
+    c = [c for c in cases if c['op'] == 'layout'][0]
+    lay = T(arr['lay']).float() / 255
+    pf = IU.generate_pseudo_fake(lay)
+    assert np.array_equal((pf * 255).round().to(torch.uint8).numpy(), arr['pseudo_fake_u8'])
+    outs = IU.make_batch_for_local_d(lay, c['sizes'], to_minus11=True)
+    for k, o in enumerate(outs):
+        np.testing.assert_allclose(o.numpy(), arr[f'local_d_{k}'], rtol=0, atol=1e-7)
+    # single-image helpers agree with the batched path
+    crop = IU.crop_to_content(lay[0, 0])
+    assert crop.shape == (4, 29, 59)            # the max row/column is excluded, as upstream
+    np.testing.assert_allclose(IU.pad_256(crop).numpy(), pf[0, 0].numpy(), atol=0)
+    assert IU.crop_to_content(lay[1, 1]).shape == (4, 0, 0)        # empty layer
