@@ -125,6 +125,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--prof-steps', type=int, default=4, help='extra (untimed) steps with per-kernel HIP events for the roofline object')
     ap.add_argument('--no-stats', action='store_true', help='turn training_stats.report into a no-op')
+    ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark=True (MIOpen exhaustive find; minutes of warm-up on a fresh box)')
+    ap.add_argument('--quiet', action='store_true')
     args = ap.parse_args()
     if args.batch_gpu is None:
         args.batch_gpu = 8 if args.workload == 'aio' else 32
@@ -147,21 +149,35 @@ def main():
     mod('torch_utils.custom_ops').verbosity = 'none'
 
     trainer, workload = build_trainer(args, device, rank, world)
+    # MIOpen: immediate-mode solver selection unless asked otherwise; the loops' default (find mode, as upstream's
+    # cudnn.benchmark=True) costs minutes of search per fresh box and would dominate a short benchmark.
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+
+    def progress(msg):
+        if rank == 0 and not args.quiet:
+            print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+    progress(f'built {workload}; batch/gpu {args.batch_gpu}; phases {len(trainer.phases)}')
 
     def sync_all():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        t_w = time.perf_counter()
         trainer.run_iteration()
+        torch.cuda.synchronize(device)
+        progress(f'warmup {i}: {time.perf_counter() - t_w:.2f} s')
     sync_all()
     counts0 = native.launch_counts()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         trainer.run_iteration()
+        if (i + 1) % 4 == 0:
+            progress(f'step {i + 1}/{args.steps} enqueued at +{time.perf_counter() - t0:.2f} s')
     sync_all()
     elapsed = time.perf_counter() - t0
+    progress(f'timed region: {elapsed:.2f} s')
     counts1 = native.launch_counts()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
