@@ -72,7 +72,9 @@ def cpu_baseline(args):
     for aio, the other L-1 local GANs and the global GAN; the sample is scaled by L only, so the reported CPU
     rate is an UPPER bound."""
     NW, LS = mod('training.networks'), mod('training.loss')
-    threads = int(os.environ.get('BENCH_CPU_THREADS', os.cpu_count() or 1))
+    # the GPU box gives one GPU a share of 16 host cores: never oversubscribe it
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    threads = int(os.environ.get('BENCH_CPU_THREADS', min(avail, 16)))
     torch.set_num_threads(threads)
     b = args.cpu_batch
     cci = 3 if args.workload == 'aio' else 2
@@ -96,7 +98,10 @@ def cpu_baseline(args):
                 m.requires_grad_(False)
                 for p in m.parameters():
                     p.grad = None
+    print(f'[bench] cpu_baseline: {threads} threads, batch {b} ...', file=sys.stderr, flush=True)
+    t_w = time.time()
     one()                                   # warm-up
+    print(f'[bench] cpu_baseline warm-up {time.time() - t_w:.1f} s', file=sys.stderr, flush=True)
     t0 = time.time()
     reps = 0
     while reps < 1 or (time.time() - t0 < args.cpu_seconds and reps < 8):
