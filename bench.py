@@ -132,6 +132,7 @@ def main():
     ap.add_argument('--no-stats', action='store_true', help='turn training_stats.report into a no-op')
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark=True (MIOpen exhaustive find; minutes of warm-up on a fresh box)')
     ap.add_argument('--quiet', action='store_true')
+    ap.add_argument('--marker-file', default=None, help='write clock readings at the start/end of the timed region (for cutting a rocprofv3 trace)')
     args = ap.parse_args()
     if args.batch_gpu is None:
         args.batch_gpu = 8 if args.workload == 'aio' else 32
@@ -175,6 +176,10 @@ def main():
         progress(f'warmup {i}: {time.perf_counter() - t_w:.2f} s')
     sync_all()
     counts0 = native.launch_counts()
+
+    def clocks():
+        return {n: time.clock_gettime_ns(getattr(time, n)) for n in ('CLOCK_MONOTONIC', 'CLOCK_BOOTTIME', 'CLOCK_REALTIME', 'CLOCK_MONOTONIC_RAW')}
+    mark0 = clocks()
     t0 = time.perf_counter()
     for i in range(args.steps):
         trainer.run_iteration()
@@ -183,6 +188,8 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     progress(f'timed region: {elapsed:.2f} s')
+    if args.marker_file and rank == 0:
+        json.dump(dict(start=mark0, end=clocks(), steps=args.steps), open(args.marker_file, 'w'))
     counts1 = native.launch_counts()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
