@@ -47,6 +47,10 @@ def build_trainer(args, device, rank, world):
         if args.tiny:
             for k in ('local_G_kwargs', 'local_D_kwargs', 'global_D_kwargs'):
                 kw[k].channel_base, kw[k].channel_max = 512, 32
+        if args.channels_last:
+            kw.local_G_kwargs.fp16_channels_last = True
+            kw.local_D_kwargs.block_kwargs.fp16_channels_last = True
+            kw.global_D_kwargs.block_kwargs.fp16_channels_last = True
         cfg = dict(TL.config, bypass_renderer=True)
         reals = [DS.synthetic_layers(args.batch_gpu, args.layers, args.res, seed=1000 * rank + i, device=device) for i in range(2)]
         trainer = TL.AioTrainer(rank=rank, device=device, cfg=cfg, resident_batches=reals, random_seed=0, **kw)
@@ -132,6 +136,7 @@ def main():
     ap.add_argument('--no-stats', action='store_true', help='turn training_stats.report into a no-op')
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark=True (MIOpen exhaustive find; minutes of warm-up on a fresh box)')
     ap.add_argument('--quiet', action='store_true')
+    ap.add_argument('--channels-last', action='store_true', help='experiment: NHWC activations in the reduced-precision blocks')
     ap.add_argument('--marker-file', default=None, help='write clock readings at the start/end of the timed region (for cutting a rocprofv3 trace)')
     args = ap.parse_args()
     if args.batch_gpu is None:
