@@ -234,6 +234,158 @@ void launch_tiled(const UfParams& p, hipStream_t s)
     else         launch_tiled_phase<T, UPX, UPY, DNX, DNY, FW, FH, 0, (UPY > 1), MX, MY>(p, s);
 }
 
+
+// ---------------------------------------------------------------------------
+// Streaming kernel for up = down = 1, filters up to 4x4, dense NCHW -- the blur that follows every
+// up-sampling convolution of G and precedes every down-sampling convolution of D (and their
+// gradients): the dominant upfirdn2d configuration of the training step.
+//
+// No LDS, no barrier.  One WAVE owns a strip of 64*CPL input columns of one plane and walks down
+// RH output rows: per input row every lane loads CPL adjacent samples with ONE coalesced access
+// (4 bytes: one float, or an aligned pair of 16-bit values), the FW-1 right-hand neighbours arrive
+// by wave shuffles, and a ring of FH accumulators per column carries the vertical taps, so every
+// input sample is read from HBM once (plus a (FW-1)/(64*CPL) / (FH-1)/RH halo) and costs FW*FH MACs.
+template <class T> struct StreamTraits { static constexpr int CPL = 1; };
+template <> struct StreamTraits<mg_half> { static constexpr int CPL = 2; };
+template <> struct StreamTraits<mg_bf16> { static constexpr int CPL = 2; };
+
+template <class T> __device__ __forceinline__ float raw16_to_f32(unsigned r);
+template <> __device__ __forceinline__ float raw16_to_f32<mg_bf16>(unsigned r) { return __builtin_bit_cast(float, r << 16); }
+template <> __device__ __forceinline__ float raw16_to_f32<mg_half>(unsigned r) { return (float)__builtin_bit_cast(mg_half, (unsigned short)r); }
+template <class T> __device__ __forceinline__ unsigned f32_to_raw16(float v) { return (unsigned)__builtin_bit_cast(unsigned short, from_acc<T>(v)); }
+
+constexpr int US_FW = 4, US_FH = 4;
+
+template <class T, int RH>
+__global__ void __launch_bounds__(256) upfirdn2d_stream(UfParams p, int nstrips, int nchunks, uint32_t ntasks)
+{
+    constexpr int CPL = StreamTraits<T>::CPL;
+    constexpr int FW = US_FW, FH = US_FH;
+    constexpr int OWW = (64 * CPL - (FW - 1)) & ~(CPL - 1);       // outputs per strip (even for CPL = 2)
+    const int lane = threadIdx.x & 63;
+    const uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (task >= ntasks) return;                                     // wave-uniform
+    const int strip = task % nstrips, chunk = (task / nstrips) % nchunks, plane = task / (nstrips * nchunks);
+
+    float ft[FH][FW];
+    #pragma unroll
+    for (int ky = 0; ky < FH; ky++)
+        #pragma unroll
+        for (int kx = 0; kx < FW; kx++) {
+            float v = 0.f;
+            if (kx < p.f_w && ky < p.f_h)
+                v = p.f[(p.flip ? ky : p.f_h - 1 - ky) * p.fs_h + (p.flip ? kx : p.f_w - 1 - kx) * p.fs_w];
+            ft[ky][kx] = v;
+        }
+
+    const int out_x0 = strip * OWW, out_y0 = chunk * RH;
+    const int in_x0 = out_x0 - p.padx0, in_y0 = out_y0 - p.pady0;   // up = down = 1: mid = o - pad0
+    const int rows_out = min(RH, p.out_h - out_y0);
+    const int64_t plane_in = (int64_t)plane * p.in_h * p.in_w;
+    const int64_t total_in = (int64_t)p.n * p.c * p.in_h * p.in_w;
+    const T* __restrict__ xin = (const T*)p.x;
+    T* __restrict__ yout = (T*)p.y + (int64_t)plane * p.out_h * p.out_w;
+    const int col0 = in_x0 + lane * CPL;                            // first input column owned by this lane
+
+    float acc[FH][CPL];
+    #pragma unroll
+    for (int a = 0; a < FH; a++)
+        #pragma unroll
+        for (int q = 0; q < CPL; q++) acc[a][q] = 0.f;
+
+    const int rows_in = rows_out + FH - 1;
+    for (int jb = 0; jb < rows_in; jb += FH) {
+        // issue the loads of FH rows first, then consume them
+        float own[FH][CPL];
+        #pragma unroll
+        for (int r = 0; r < FH; r++) {
+            const int j = jb + r, iy = in_y0 + j;
+            #pragma unroll
+            for (int q = 0; q < CPL; q++) own[r][q] = 0.f;
+            if (j >= rows_in || iy < 0 || iy >= p.in_h) continue;   // wave-uniform
+            const int64_t e0 = plane_in + (int64_t)iy * p.in_w + in_x0;
+            if constexpr (CPL == 1) {
+                if (col0 >= 0 && col0 < p.in_w) own[r][0] = (float)to_acc<T>(xin[e0 + lane]);
+            } else {
+                // aligned pair containing element e0 + 2*lane - par, par = parity of the row start
+                const int par = (int)(e0 & 1);
+                const int64_t E = e0 - par + 2 * (int64_t)lane;
+                unsigned w = 0;
+                if (E >= 0 && E + 1 < total_in) w = *(const unsigned*)(xin + E);
+                else {
+                    if (E >= 0 && E < total_in) w = (unsigned)__builtin_bit_cast(unsigned short, xin[E]);
+                    if (E + 1 >= 0 && E + 1 < total_in) w |= (unsigned)__builtin_bit_cast(unsigned short, xin[E + 1]) << 16;
+                }
+                unsigned lo = w & 0xffffu, hi = w >> 16;
+                if (par) {                                          // shift left by one column
+                    unsigned nxt = (unsigned)__shfl_down((int)w, 1, 64);
+                    lo = hi; hi = nxt & 0xffffu;
+                }
+                const bool v0 = col0 >= 0 && col0 < p.in_w, v1 = col0 + 1 >= 0 && col0 + 1 < p.in_w;
+                own[r][0] = v0 ? raw16_to_f32<T>(lo) : 0.f;
+                own[r][1] = v1 ? raw16_to_f32<T>(hi) : 0.f;
+            }
+        }
+        #pragma unroll
+        for (int r = 0; r < FH; r++) {
+            const int j = jb + r;
+            if (j >= rows_in) break;                                // wave-uniform
+            // columns col0 .. col0 + CPL + FW - 2 of input row j
+            float v[CPL + FW - 1];
+            #pragma unroll
+            for (int q = 0; q < CPL; q++) v[q] = own[r][q];
+            #pragma unroll
+            for (int k = CPL; k < CPL + FW - 1; k++) v[k] = __shfl_down(own[r][k % CPL], k / CPL, 64);
+            // row j carries tap ky of output row j - ky; ring slot (j - ky) mod FH = (r - ky) mod FH
+            #pragma unroll
+            for (int ky = 0; ky < FH; ky++) {
+                const int slot = ((r - ky) % FH + FH) % FH;
+                #pragma unroll
+                for (int q = 0; q < CPL; q++)
+                    #pragma unroll
+                    for (int kx = 0; kx < FW; kx++) acc[slot][q] += v[q + kx] * ft[ky][kx];
+            }
+            // output row j - (FH-1) is complete; its slot is (r + 1) mod FH
+            const int oy = j - (FH - 1);
+            const int done = (r + 1) % FH;
+            if (oy >= 0) {
+                const int ox = out_x0 + lane * CPL;
+                T* row = yout + (int64_t)(out_y0 + oy) * p.out_w;
+                if (lane * CPL < OWW) {
+                    if constexpr (CPL == 1) {
+                        if (ox < p.out_w) row[ox] = from_acc<T>(acc[done][0] * p.gain);
+                    } else {
+                        const unsigned a = f32_to_raw16<T>(acc[done][0] * p.gain), b = f32_to_raw16<T>(acc[done][CPL - 1] * p.gain);
+                        if (ox + 1 < p.out_w && (((uintptr_t)(row + ox)) & 3) == 0) *(unsigned*)(row + ox) = a | (b << 16);
+                        else {
+                            if (ox < p.out_w) row[ox] = __builtin_bit_cast(T, (unsigned short)a);
+                            if (ox + 1 < p.out_w) row[ox + 1] = __builtin_bit_cast(T, (unsigned short)b);
+                        }
+                    }
+                }
+            }
+            #pragma unroll
+            for (int q = 0; q < CPL; q++) acc[done][q] = 0.f;
+        }
+    }
+}
+
+template <class T>
+bool try_stream(const UfParams& p, hipStream_t s)
+{
+    constexpr int CPL = StreamTraits<T>::CPL;
+    constexpr int OWW = (64 * CPL - (US_FW - 1)) & ~(CPL - 1);
+    constexpr int RH = 64;
+    if (!(p.upx == 1 && p.upy == 1 && p.downx == 1 && p.downy == 1 && p.f_w <= US_FW && p.f_h <= US_FH)) return false;
+    if (p.out_w < 48) return false;                                 // small planes: the tiled kernel packs several per workgroup
+    int nstrips = (p.out_w + OWW - 1) / OWW, nchunks = (p.out_h + RH - 1) / RH;
+    int64_t ntasks = (int64_t)nstrips * nchunks * p.n * p.c;
+    if (ntasks > (int64_t)UINT32_MAX / 2) return false;
+    uint32_t blocks = (uint32_t)((ntasks + 3) / 4);
+    hipLaunchKernelGGL((upfirdn2d_stream<T, RH>), dim3(blocks), dim3(256), 0, s, p, nstrips, nchunks, (uint32_t)ntasks);
+    return true;
+}
+
 // Returns true when a tiled specialisation took the call.
 template <class T>
 bool try_tiled(const UfParams& p, hipStream_t s)
@@ -242,6 +394,7 @@ bool try_tiled(const UfParams& p, hipStream_t s)
                        p.xs_n == (int64_t)p.c * p.in_h * p.in_w && p.ys_w == 1 && p.ys_h == p.out_w &&
                        p.ys_c == (int64_t)p.out_h * p.out_w && p.ys_n == (int64_t)p.c * p.out_h * p.out_w;
     if (!dense) return false;
+    if (sizeof(T) <= 4 && try_stream<T>(p, s)) return true;
     const int ux = p.upx, uy = p.upy, dx = p.downx, dy = p.downy, fw = p.f_w, fh = p.f_h;
 #define UF_CASE(UX, UY, DX, DY, FW_, FH_, MX_, MY_)                                                       \
     if (ux == UX && uy == UY && dx == DX && dy == DY && fw <= FW_ && fh <= FH_) {                         \

@@ -123,6 +123,35 @@ def test_upfirdn2d_integer_data_bit_exact(native, oracle, flip):
         assert np.array_equal(got.cpu().numpy(), want), (shape, up, down, pad, fk, flip)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+def test_upfirdn2d_stream_kernel_bit_exact_and_edges(native, oracle, dtype):
+    """The wave-shuffle streaming kernel (up = down = 1, <= 4x4 taps, width >= 48): odd and even row
+    pitches (both 16-bit pair alignments), every pad sign, strip/chunk boundaries, exact on small integers."""
+    rng = np.random.RandomState(21)
+    plugin = custom_ops().get_plugin('upfirdn2d_plugin')
+    lo, hi = (-8, 9) if dtype != torch.bfloat16 else (-1, 2)
+    taps = {'k4': [1, 3, 3, 1], 'k3': [1, 2, 1], 'k2': [1, 1]} if dtype != torch.bfloat16 else {'k2': [1, 1], 'k4b': [1, 1, 1, 1]}
+    for shape in ([2, 3, 257, 257], [1, 2, 64, 125], [1, 2, 70, 124], [3, 1, 131, 250], [1, 1, 5, 49], [2, 2, 48, 48], [1, 3, 129, 383]):
+        for pad in ([1, 1, 1, 1], [2, 2, 2, 2], [0, 0, 0, 0], [3, 0, -1, 2], [-2, 3, 1, 1]):
+            for fk, tp in taps.items():
+                v = np.asarray(tp, dtype=np.float32)
+                f = np.outer(v, v)
+                if shape[2] + pad[2] + pad[3] - f.shape[0] + 1 < 1 or shape[3] + pad[0] + pad[1] - f.shape[1] + 1 < 48:
+                    continue
+                x = rng.randint(lo, hi, size=shape).astype(np.float32)
+                for flip in (False, True):
+                    want = oracle.upfirdn2d(x, f, (1, 1), (1, 1), tuple(pad), flip, 1.0)
+                    got = plugin.upfirdn2d(T(x).to(dtype).to(DEV), T(f).to(DEV), 1, 1, 1, 1, pad[0], pad[1], pad[2], pad[3], flip, 1.0)
+                    assert got.dtype == dtype and tuple(got.shape) == want.shape
+                    assert np.array_equal(got.float().cpu().numpy(), want), (shape, pad, fk, flip, dtype)
+    # random data, asymmetric filter, gain
+    f = rng.randn(3, 4).astype(np.float32)
+    x = rng.randn(2, 3, 100, 131).astype(np.float32)
+    want = oracle.upfirdn2d(T(x).to(dtype).float().numpy(), f, (1, 1), (1, 1), (2, 1, 1, 1), False, 2.5)
+    got = plugin.upfirdn2d(T(x).to(dtype).to(DEV), T(f).to(DEV), 1, 1, 1, 1, 2, 1, 1, 1, False, 2.5)
+    close_lowp(got.float().cpu().numpy(), want, dtype, 'stream random')
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16, torch.float64])
 def test_upfirdn2d_dtypes_vs_oracle(native, oracle, dtype):
     rng = np.random.RandomState(11)

@@ -56,7 +56,7 @@ def main():
     rec('copy_ (256 MiB)', timeit(lambda: dst.copy_(big)), 2 * big.numel() * es)
     del big, dst
 
-    for r, c in [(256, 64), (128, 128), (64, 256), (32, 512), (16, 512)]:
+    for r, c in [(256, 64), (128, 128), (64, 256), (32, 512)]:
         x = torch.randn([n, c, r, r], device=dev).to(dt)
         b = torch.randn([c], device=dev).to(dt)
         rec(f'bias_act lrelu fwd [{n},{c},{r},{r}]', timeit(lambda: B.bias_act(x, b, act='lrelu', clamp=256)), 2 * x.numel() * es)
