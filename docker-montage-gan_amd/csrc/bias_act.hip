@@ -26,13 +26,19 @@ template <class T> __device__ __forceinline__ uint32_t ba_bias_index(uint32_t i,
 
 // VEC elements per lane per access (16 bytes, or 1 when pointers are unaligned);
 // U accesses in flight per lane.  BVEC: bias index is uniform inside one vector.
-template <class T, int A, int VEC, int U, bool BVEC>
-__global__ void __launch_bounds__(256) bias_act_kernel(BaArgs<T> p)
+// GT: gradient order known at compile time (0 or 1; -1 = read p.grad).  With GT fixed the loads that
+// order never needs (xref/yref/dy at order 0; b/xref/dy for the 'y'-referenced activations at order 1)
+// and their null checks disappear from the per-element code.
+template <class T, int A, int VEC, int U, bool BVEC, int GT>
+__global__ void __launch_bounds__(256) bias_act_kernel(BaArgs<T> p0)
 {
     typedef typename Acc<T>::type acc_t;
     struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
+    BaArgs<T> p = p0;
+    if (GT == 0) { p.xref = nullptr; p.yref = nullptr; p.dy = nullptr; }
+    if (GT == 1) { p.dy = nullptr; if (A <= 8) { p.xref = nullptr; p.b = nullptr; } }
     const BaConst<acc_t> k = {(acc_t)p.alpha, (acc_t)p.gain, (acc_t)p.clamp};
-    const int G = p.grad;
+    const int G = (GT >= 0) ? GT : p.grad;
     const uint32_t nvec = p.size_x / VEC;
     const uint32_t chunk = 256u * U;
     for (uint32_t base = blockIdx.x * chunk; base < nvec; base += gridDim.x * chunk) {
@@ -78,8 +84,8 @@ __global__ void __launch_bounds__(256) bias_act_kernel(BaArgs<T> p)
     }
 }
 
-template <class T, int A>
-int launch_bias_act(const BaArgs<T>& p, bool aligned, bool bvec, hipStream_t stream)
+template <class T, int A, int GT>
+void launch_bias_act_g(const BaArgs<T>& p, bool aligned, bool bvec, hipStream_t stream)
 {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int U = 4;
@@ -88,13 +94,22 @@ int launch_bias_act(const BaArgs<T>& p, bool aligned, bool bvec, hipStream_t str
         uint32_t nvec = p.size_x / VEC;
         uint32_t blocks = (nvec + 256u * U - 1) / (256u * U);
         blocks = blocks < 1 ? 1 : (blocks > max_blocks ? max_blocks : blocks);
-        if (bvec) hipLaunchKernelGGL((bias_act_kernel<T, A, VEC, U, true>), dim3(blocks), dim3(256), 0, stream, p);
-        else      hipLaunchKernelGGL((bias_act_kernel<T, A, VEC, U, false>), dim3(blocks), dim3(256), 0, stream, p);
+        if (bvec) hipLaunchKernelGGL((bias_act_kernel<T, A, VEC, U, true, GT>), dim3(blocks), dim3(256), 0, stream, p);
+        else      hipLaunchKernelGGL((bias_act_kernel<T, A, VEC, U, false, GT>), dim3(blocks), dim3(256), 0, stream, p);
     } else {
         uint32_t blocks = (p.size_x + 256u * U - 1) / (256u * U);
         blocks = blocks < 1 ? 1 : (blocks > max_blocks ? max_blocks : blocks);
-        hipLaunchKernelGGL((bias_act_kernel<T, A, 1, U, true>), dim3(blocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((bias_act_kernel<T, A, 1, U, true, GT>), dim3(blocks), dim3(256), 0, stream, p);
     }
+}
+
+template <class T, int A>
+int launch_bias_act(const BaArgs<T>& p, bool aligned, bool bvec, hipStream_t stream)
+{
+    // linear / relu / lrelu are what the networks run: orders 0 and 1 get their own code
+    if (A <= 3 && p.grad == 0)      launch_bias_act_g<T, A, (A <= 3 ? 0 : -1)>(p, aligned, bvec, stream);
+    else if (A <= 3 && p.grad == 1) launch_bias_act_g<T, A, (A <= 3 ? 1 : -1)>(p, aligned, bvec, stream);
+    else                            launch_bias_act_g<T, A, -1>(p, aligned, bvec, stream);
     return mg_check_launch(MG_K_BIAS_ACT, "bias_act");
 }
 

@@ -21,30 +21,55 @@ template <class T> struct FbArgs {
 };
 
 // forward.  One lane = one 16-byte vector inside one (n,c) plane (hw % VEC == 0) or one element.
+// U vectors (and their noise) are requested before any is consumed; grid-stride over chunks.
+constexpr int FB_U = 4;
+
 template <class T, int A, int VEC>
 __global__ void __launch_bounds__(256) fma_bias_act_fwd_kernel(FbArgs<T> p)
 {
     struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
+    struct alignas(VEC >= 4 ? 16 : 4) NV { float v[VEC]; };
     const BaConst<float> k = {p.alpha, p.gain, p.clamp};
     const uint32_t hwv = p.hw / VEC;
-    for (uint32_t vi = blockIdx.x * 256u + threadIdx.x; vi < p.total_vec; vi += gridDim.x * 256u) {
-        uint32_t plane = fd_div(vi, p.hwv_div), pv = vi - plane * hwv;
-        V xin = ((const V*)p.x)[vi];
-        float dc = p.d ? p.d[plane] : 1.f;
-        float bb = 0.f;
-        const uint32_t n = fd_div(plane, p.c_div);
-        if (p.b) bb = to_acc<T>(p.b[plane - n * p.c]);
-        const float* nz = p.noise ? p.noise + (int64_t)n * p.noise_stride_n + (size_t)pv * VEC : nullptr;
-        V out;
+    const bool nz_vec = (VEC == 1) || ((((uintptr_t)p.noise) & 15) == 0 && ((p.noise_stride_n * 4) & 15) == 0);
+    for (uint32_t base = blockIdx.x * (256u * FB_U); base < p.total_vec; base += gridDim.x * (256u * FB_U)) {
+        V xin[FB_U];
+        NV nzv[FB_U];
+        uint32_t plane[FB_U];
         #pragma unroll
-        for (int e = 0; e < VEC; e++) {
-            float v = to_acc<T>(xin.v[e]) * dc;
-            if (nz) v += nz[e] * p.noise_gain;
-            // the reference rounds the fma result to T before bias_act reads it back
-            v = to_acc<T>(from_acc<T>(v));
-            out.v[e] = from_acc<T>(ba_eval<float, A>(0, v, bb, 0.f, 0.f, 1.f, k));
+        for (int u = 0; u < FB_U; u++) {
+            const uint32_t vi = base + u * 256u + threadIdx.x;
+            if (vi >= p.total_vec) continue;
+            plane[u] = fd_div(vi, p.hwv_div);
+            xin[u] = ((const V*)p.x)[vi];
+            if (p.noise) {
+                const uint32_t pv = vi - plane[u] * hwv, n = fd_div(plane[u], p.c_div);
+                const float* nz = p.noise + (int64_t)n * p.noise_stride_n + (size_t)pv * VEC;
+                if (nz_vec) nzv[u] = *(const NV*)nz;
+                else {
+                    #pragma unroll
+                    for (int e = 0; e < VEC; e++) nzv[u].v[e] = nz[e];
+                }
+            }
         }
-        ((V*)p.y)[vi] = out;
+        #pragma unroll
+        for (int u = 0; u < FB_U; u++) {
+            const uint32_t vi = base + u * 256u + threadIdx.x;
+            if (vi >= p.total_vec) continue;
+            const float dc = p.d ? p.d[plane[u]] : 1.f;
+            float bb = 0.f;
+            if (p.b) { const uint32_t n = fd_div(plane[u], p.c_div); bb = to_acc<T>(p.b[plane[u] - n * p.c]); }
+            V out;
+            #pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                float v = to_acc<T>(xin[u].v[e]) * dc;
+                if (p.noise) v += nzv[u].v[e] * p.noise_gain;
+                // the reference rounds the fma result to T before bias_act reads it back
+                v = to_acc<T>(from_acc<T>(v));
+                out.v[e] = from_acc<T>(ba_eval<float, A>(0, v, bb, 0.f, 0.f, 1.f, k));
+            }
+            ((V*)p.y)[vi] = out;
+        }
     }
 }
 
@@ -54,20 +79,31 @@ __global__ void __launch_bounds__(256) fma_bias_act_bwd_kernel(FbArgs<T> p)
 {
     struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
     const BaConst<float> k = {p.alpha, p.gain, p.clamp};
-    for (uint32_t vi = blockIdx.x * 256u + threadIdx.x; vi < p.total_vec; vi += gridDim.x * 256u) {
-        uint32_t plane = fd_div(vi, p.hwv_div);
-        V dy = ((const V*)p.x)[vi], yr = ((const V*)p.b)[vi];
-        float dc = p.d ? p.d[plane] : 1.f;
-        V o1, o2;
+    for (uint32_t base = blockIdx.x * (256u * FB_U); base < p.total_vec; base += gridDim.x * (256u * FB_U)) {
+        V dy[FB_U], yr[FB_U];
         #pragma unroll
-        for (int e = 0; e < VEC; e++) {
-            float g = ba_eval<float, A>(1, to_acc<T>(dy.v[e]), 0.f, 0.f, to_acc<T>(yr.v[e]), 1.f, k);
-            o2.v[e] = from_acc<T>(g);
-            // dx is the gradient through fma of the T-rounded bias_act gradient
-            o1.v[e] = from_acc<T>(to_acc<T>(o2.v[e]) * dc);
+        for (int u = 0; u < FB_U; u++) {
+            const uint32_t vi = base + u * 256u + threadIdx.x;
+            if (vi >= p.total_vec) continue;
+            dy[u] = ((const V*)p.x)[vi];
+            yr[u] = ((const V*)p.b)[vi];
         }
-        ((V*)p.y)[vi] = o1;
-        if (p.y2) ((V*)p.y2)[vi] = o2;
+        #pragma unroll
+        for (int u = 0; u < FB_U; u++) {
+            const uint32_t vi = base + u * 256u + threadIdx.x;
+            if (vi >= p.total_vec) continue;
+            const float dc = p.d ? p.d[fd_div(vi, p.hwv_div)] : 1.f;
+            V o1, o2;
+            #pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                float g = ba_eval<float, A>(1, to_acc<T>(dy[u].v[e]), 0.f, 0.f, to_acc<T>(yr[u].v[e]), 1.f, k);
+                o2.v[e] = from_acc<T>(g);
+                // dx is the gradient through fma of the T-rounded bias_act gradient
+                o1.v[e] = from_acc<T>(to_acc<T>(o2.v[e]) * dc);
+            }
+            ((V*)p.y)[vi] = o1;
+            if (p.y2) ((V*)p.y2)[vi] = o2;
+        }
     }
 }
 
@@ -79,8 +115,8 @@ void launch_fb(const FbArgs<T>& p0, bool bwd, bool wide, hipStream_t s)
     int vec = wide ? VEC : 1;
     p.hwv_div = make_fastdiv(p.hw / vec);
     p.total_vec = p.total_vec / vec;
-    uint32_t blocks = (p.total_vec + 255u) / 256u;
-    if (blocks > 256u * 16u) blocks = 256u * 16u;
+    uint32_t blocks = (p.total_vec + 256u * FB_U - 1) / (256u * FB_U);
+    if (blocks > 256u * 8u) blocks = 256u * 8u;
     if (blocks < 1) blocks = 1;
     if (!bwd) {
         if (wide) hipLaunchKernelGGL((fma_bias_act_fwd_kernel<T, A, VEC>), dim3(blocks), dim3(256), 0, s, p);

@@ -15,7 +15,11 @@ __device__ __forceinline__ acc_t ba_eval(int G, acc_t x, acc_t b, acc_t xref, ac
     const acc_t one = 1, two = 2, expRange = 80, halfExpRange = 40;
     const acc_t seluScale = (acc_t)1.0507009873554804934193349852946;
     const acc_t seluAlpha = (acc_t)1.6732632423543772848170429916717;
-    acc_t yy = (k.gain != 0) ? yref / k.gain : 0;
+    // yy = yref / gain (bias_act.cu:48).  relu/lrelu only ask whether yy > 0, which the sign of gain
+    // answers without an IEEE division per element; linear never reads it.
+    acc_t yy;
+    if (A <= 3) yy = (k.gain > 0) ? yref : (k.gain < 0) ? -yref : 0;
+    else        yy = (k.gain != 0) ? yref / k.gain : 0;
     acc_t y = 0;
     if (G == 0) x += b; else xref += b;
 

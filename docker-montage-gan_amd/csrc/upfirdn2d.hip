@@ -294,40 +294,49 @@ __global__ void __launch_bounds__(256) upfirdn2d_stream(UfParams p, int nstrips,
         for (int q = 0; q < CPL; q++) acc[a][q] = 0.f;
 
     const int rows_in = rows_out + FH - 1;
-    for (int jb = 0; jb < rows_in; jb += FH) {
-        // issue the loads of FH rows first, then consume them
-        float own[FH][CPL];
+    constexpr int GRP = 2 * FH;                                     // input rows in flight per wave
+    for (int jb = 0; jb < rows_in; jb += GRP) {
+        // phase 1: issue the loads of GRP rows back to back (nothing below depends on another row's data)
+        unsigned raw[GRP];
+        int par[GRP];
         #pragma unroll
-        for (int r = 0; r < FH; r++) {
+        for (int r = 0; r < GRP; r++) {
             const int j = jb + r, iy = in_y0 + j;
-            #pragma unroll
-            for (int q = 0; q < CPL; q++) own[r][q] = 0.f;
+            raw[r] = 0; par[r] = 0;
             if (j >= rows_in || iy < 0 || iy >= p.in_h) continue;   // wave-uniform
             const int64_t e0 = plane_in + (int64_t)iy * p.in_w + in_x0;
             if constexpr (CPL == 1) {
-                if (col0 >= 0 && col0 < p.in_w) own[r][0] = (float)to_acc<T>(xin[e0 + lane]);
+                if (col0 >= 0 && col0 < p.in_w) raw[r] = __builtin_bit_cast(unsigned, (float)to_acc<T>(xin[e0 + lane]));
             } else {
                 // aligned pair containing element e0 + 2*lane - par, par = parity of the row start
-                const int par = (int)(e0 & 1);
-                const int64_t E = e0 - par + 2 * (int64_t)lane;
-                unsigned w = 0;
-                if (E >= 0 && E + 1 < total_in) w = *(const unsigned*)(xin + E);
+                par[r] = (int)(e0 & 1);
+                const int64_t E = e0 - par[r] + 2 * (int64_t)lane;
+                if (E >= 0 && E + 1 < total_in) raw[r] = *(const unsigned*)(xin + E);
                 else {
-                    if (E >= 0 && E < total_in) w = (unsigned)__builtin_bit_cast(unsigned short, xin[E]);
-                    if (E + 1 >= 0 && E + 1 < total_in) w |= (unsigned)__builtin_bit_cast(unsigned short, xin[E + 1]) << 16;
+                    if (E >= 0 && E < total_in) raw[r] = (unsigned)__builtin_bit_cast(unsigned short, xin[E]);
+                    if (E + 1 >= 0 && E + 1 < total_in) raw[r] |= (unsigned)__builtin_bit_cast(unsigned short, xin[E + 1]) << 16;
                 }
-                unsigned lo = w & 0xffffu, hi = w >> 16;
-                if (par) {                                          // shift left by one column
-                    unsigned nxt = (unsigned)__shfl_down((int)w, 1, 64);
+            }
+        }
+        // phase 2: realign 16-bit pairs, convert, mask columns outside the image
+        float own[GRP][CPL];
+        #pragma unroll
+        for (int r = 0; r < GRP; r++) {
+            if constexpr (CPL == 1) {
+                own[r][0] = __builtin_bit_cast(float, raw[r]);
+            } else {
+                unsigned lo = raw[r] & 0xffffu, hi = raw[r] >> 16;
+                if (par[r]) {                                       // wave-uniform: shift left by one column
+                    unsigned nxt = (unsigned)__shfl_down((int)raw[r], 1, 64);
                     lo = hi; hi = nxt & 0xffffu;
                 }
                 const bool v0 = col0 >= 0 && col0 < p.in_w, v1 = col0 + 1 >= 0 && col0 + 1 < p.in_w;
                 own[r][0] = v0 ? raw16_to_f32<T>(lo) : 0.f;
-                own[r][1] = v1 ? raw16_to_f32<T>(hi) : 0.f;
+                own[r][CPL - 1] = v1 ? raw16_to_f32<T>(hi) : 0.f;
             }
         }
         #pragma unroll
-        for (int r = 0; r < FH; r++) {
+        for (int r = 0; r < GRP; r++) {
             const int j = jb + r;
             if (j >= rows_in) break;                                // wave-uniform
             // columns col0 .. col0 + CPL + FW - 2 of input row j
