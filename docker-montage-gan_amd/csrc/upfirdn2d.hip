@@ -262,8 +262,9 @@ __global__ void __launch_bounds__(256) upfirdn2d_stream(UfParams p, int nstrips,
     constexpr int CPL = StreamTraits<T>::CPL;
     constexpr int FW = US_FW, FH = US_FH;
     constexpr int OWW = (64 * CPL - (FW - 1)) & ~(CPL - 1);       // outputs per strip (even for CPL = 2)
+    constexpr int GRP = 2 * FH;                                     // input rows in flight per wave
     const int lane = threadIdx.x & 63;
-    const uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (task >= ntasks) return;                                     // wave-uniform
     const int strip = task % nstrips, chunk = (task / nstrips) % nchunks, plane = task / (nstrips * nchunks);
 
@@ -275,17 +276,33 @@ __global__ void __launch_bounds__(256) upfirdn2d_stream(UfParams p, int nstrips,
             float v = 0.f;
             if (kx < p.f_w && ky < p.f_h)
                 v = p.f[(p.flip ? ky : p.f_h - 1 - ky) * p.fs_h + (p.flip ? kx : p.f_w - 1 - kx) * p.fs_w];
-            ft[ky][kx] = v;
+            ft[ky][kx] = v * p.gain;                                // fold the gain into the taps
         }
 
+    // wave-uniform geometry (up = down = 1: first input sample of output o is o - pad0)
     const int out_x0 = strip * OWW, out_y0 = chunk * RH;
-    const int in_x0 = out_x0 - p.padx0, in_y0 = out_y0 - p.pady0;   // up = down = 1: mid = o - pad0
-    const int rows_out = min(RH, p.out_h - out_y0);
-    const int64_t plane_in = (int64_t)plane * p.in_h * p.in_w;
+    const int in_x0 = out_x0 - p.padx0, in_y0 = out_y0 - p.pady0;
+    const int rows_out = min(RH, p.out_h - out_y0), rows_in = rows_out + FH - 1;
     const int64_t total_in = (int64_t)p.n * p.c * p.in_h * p.in_w;
+    const int64_t e_first = (int64_t)plane * p.in_h * p.in_w + (int64_t)in_y0 * p.in_w + in_x0;   // element (row 0 of the strip, col in_x0)
     const T* __restrict__ xin = (const T*)p.x;
-    T* __restrict__ yout = (T*)p.y + (int64_t)plane * p.out_h * p.out_w;
-    const int col0 = in_x0 + lane * CPL;                            // first input column owned by this lane
+    T* __restrict__ yout = (T*)p.y + (int64_t)plane * p.out_h * p.out_w + (int64_t)out_y0 * p.out_w + out_x0;
+
+    // per-lane invariants
+    const int col0 = in_x0 + lane * CPL;
+    const bool v0 = col0 >= 0 && col0 < p.in_w;
+    const bool v1 = col0 + 1 >= 0 && col0 + 1 < p.in_w;
+    const int oxl = lane * CPL;                                     // output column inside the strip
+    const bool st0 = oxl < OWW && out_x0 + oxl < p.out_w;
+    const bool st1 = oxl + 1 < OWW && out_x0 + oxl + 1 < p.out_w;
+    const T* lane_in = xin + lane * CPL;
+    T* lane_out = yout + oxl;
+    // 16-bit pairs: which halves of the lane's aligned pair are inside the image, for an even (M0) and an
+    // odd (M1: the pair starts one column to the left) row start.  Masking at the source means the
+    // neighbours' values arrive already zeroed through the shuffles.
+    const bool vm1 = col0 - 1 >= 0 && col0 - 1 < p.in_w;
+    const unsigned M0 = (v0 ? 0xffffu : 0u) | (v1 ? 0xffff0000u : 0u);
+    const unsigned M1 = (vm1 ? 0xffffu : 0u) | (v0 ? 0xffff0000u : 0u);
 
     float acc[FH][CPL];
     #pragma unroll
@@ -293,58 +310,60 @@ __global__ void __launch_bounds__(256) upfirdn2d_stream(UfParams p, int nstrips,
         #pragma unroll
         for (int q = 0; q < CPL; q++) acc[a][q] = 0.f;
 
-    const int rows_in = rows_out + FH - 1;
-    constexpr int GRP = 2 * FH;                                     // input rows in flight per wave
+    // wave-uniform running state, advanced by one row per step (no per-row multiplications)
+    int64_t e_row = e_first;                                        // element offset of (input row j, column in_x0)
+    int iy = in_y0;
+    T* out_row = lane_out - (int64_t)(FH - 1) * p.out_w;            // row j - (FH-1)
+    const int odd_pitch_out = p.out_w & 1;
+    int out_par = (int)(((((uintptr_t)yout) >> 1) + (uint64_t)(uint32_t)((FH - 1) * odd_pitch_out)) & 1);   // parity of out_row's first element
+
     for (int jb = 0; jb < rows_in; jb += GRP) {
-        // phase 1: issue the loads of GRP rows back to back (nothing below depends on another row's data)
+        // phase 1: issue the loads of GRP rows back to back
         unsigned raw[GRP];
         int par[GRP];
         #pragma unroll
         for (int r = 0; r < GRP; r++) {
-            const int j = jb + r, iy = in_y0 + j;
             raw[r] = 0; par[r] = 0;
-            if (j >= rows_in || iy < 0 || iy >= p.in_h) continue;   // wave-uniform
-            const int64_t e0 = plane_in + (int64_t)iy * p.in_w + in_x0;
-            if constexpr (CPL == 1) {
-                if (col0 >= 0 && col0 < p.in_w) raw[r] = __builtin_bit_cast(unsigned, (float)to_acc<T>(xin[e0 + lane]));
-            } else {
-                // aligned pair containing element e0 + 2*lane - par, par = parity of the row start
-                par[r] = (int)(e0 & 1);
-                const int64_t E = e0 - par[r] + 2 * (int64_t)lane;
-                if (E >= 0 && E + 1 < total_in) raw[r] = *(const unsigned*)(xin + E);
-                else {
-                    if (E >= 0 && E < total_in) raw[r] = (unsigned)__builtin_bit_cast(unsigned short, xin[E]);
-                    if (E + 1 >= 0 && E + 1 < total_in) raw[r] |= (unsigned)__builtin_bit_cast(unsigned short, xin[E + 1]) << 16;
+            const bool row_ok = (jb + r < rows_in) && iy >= 0 && iy < p.in_h;      // wave-uniform
+            if (row_ok) {
+                if constexpr (CPL == 1) {
+                    if (v0) raw[r] = __builtin_bit_cast(unsigned, (float)to_acc<T>(lane_in[e_row]));
+                } else {
+                    // one aligned 4-byte access per lane: the pair that starts at the even element
+                    // (e_row & ~1) + 2*lane; par = parity of the row start tells how it lines up with the columns
+                    par[r] = (int)(e_row & 1);
+                    const int64_t eb = e_row - par[r];
+                    if (eb >= 0 && eb + 128 <= total_in) {          // wave-uniform: whole wave inside the tensor
+                        raw[r] = *(const unsigned*)(lane_in + eb);
+                    } else {                                        // first / last row of the whole tensor
+                        const int64_t E = eb + 2 * (int64_t)lane;
+                        if (E >= 0 && E < total_in) raw[r] = (unsigned)__builtin_bit_cast(unsigned short, xin[E]);
+                        if (E + 1 >= 0 && E + 1 < total_in) raw[r] |= (unsigned)__builtin_bit_cast(unsigned short, xin[E + 1]) << 16;
+                    }
                 }
             }
+            e_row += p.in_w; iy++;
         }
-        // phase 2: realign 16-bit pairs, convert, mask columns outside the image
-        float own[GRP][CPL];
-        #pragma unroll
-        for (int r = 0; r < GRP; r++) {
-            if constexpr (CPL == 1) {
-                own[r][0] = __builtin_bit_cast(float, raw[r]);
-            } else {
-                unsigned lo = raw[r] & 0xffffu, hi = raw[r] >> 16;
-                if (par[r]) {                                       // wave-uniform: shift left by one column
-                    unsigned nxt = (unsigned)__shfl_down((int)raw[r], 1, 64);
-                    lo = hi; hi = nxt & 0xffffu;
-                }
-                const bool v0 = col0 >= 0 && col0 < p.in_w, v1 = col0 + 1 >= 0 && col0 + 1 < p.in_w;
-                own[r][0] = v0 ? raw16_to_f32<T>(lo) : 0.f;
-                own[r][CPL - 1] = v1 ? raw16_to_f32<T>(hi) : 0.f;
-            }
-        }
+        // phase 2 + 3 per row: line the pair up with the lane's columns, fetch the right-hand neighbours
+        // by wave shuffle, accumulate the FH x FW taps into the ring, retire one output row
         #pragma unroll
         for (int r = 0; r < GRP; r++) {
             const int j = jb + r;
             if (j >= rows_in) break;                                // wave-uniform
-            // columns col0 .. col0 + CPL + FW - 2 of input row j
             float v[CPL + FW - 1];
-            #pragma unroll
-            for (int q = 0; q < CPL; q++) v[q] = own[r][q];
-            #pragma unroll
-            for (int k = CPL; k < CPL + FW - 1; k++) v[k] = __shfl_down(own[r][k % CPL], k / CPL, 64);
+            if constexpr (CPL == 1) {
+                v[0] = __builtin_bit_cast(float, raw[r]);
+                #pragma unroll
+                for (int k = 1; k < FW; k++) v[k] = __shfl_down(v[0], k, 64);
+            } else {
+                const unsigned w0 = raw[r] & (par[r] ? M1 : M0);
+                const unsigned w1 = (unsigned)__shfl_down((int)w0, 1, 64);
+                const unsigned w2 = (unsigned)__shfl_down((int)w0, 2, 64);
+                // columns col0 .. col0+4 are elements par .. par+4 of the 6-element run (w0 | w1 | w2)
+                const unsigned e[6] = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, w2 & 0xffffu, w2 >> 16};
+                #pragma unroll
+                for (int k = 0; k < CPL + FW - 1; k++) v[k] = raw16_to_f32<T>(par[r] ? e[k + 1] : e[k]);
+            }
             // row j carries tap ky of output row j - ky; ring slot (j - ky) mod FH = (r - ky) mod FH
             #pragma unroll
             for (int ky = 0; ky < FH; ky++) {
@@ -352,27 +371,25 @@ __global__ void __launch_bounds__(256) upfirdn2d_stream(UfParams p, int nstrips,
                 #pragma unroll
                 for (int q = 0; q < CPL; q++)
                     #pragma unroll
-                    for (int kx = 0; kx < FW; kx++) acc[slot][q] += v[q + kx] * ft[ky][kx];
+                    for (int kx = 0; kx < FW; kx++) acc[slot][q] = __builtin_fmaf(v[q + kx], ft[ky][kx], acc[slot][q]);
             }
             // output row j - (FH-1) is complete; its slot is (r + 1) mod FH
-            const int oy = j - (FH - 1);
             const int done = (r + 1) % FH;
-            if (oy >= 0) {
-                const int ox = out_x0 + lane * CPL;
-                T* row = yout + (int64_t)(out_y0 + oy) * p.out_w;
-                if (lane * CPL < OWW) {
-                    if constexpr (CPL == 1) {
-                        if (ox < p.out_w) row[ox] = from_acc<T>(acc[done][0] * p.gain);
+            if (j >= FH - 1) {                                      // wave-uniform
+                if constexpr (CPL == 1) {
+                    if (st0) out_row[0] = from_acc<T>(acc[done][0]);
+                } else {
+                    const unsigned a = f32_to_raw16<T>(acc[done][0]), b = f32_to_raw16<T>(acc[done][CPL - 1]);
+                    if (out_par == 0) {                             // wave-uniform: 4-byte aligned row start
+                        if (st1) *(unsigned*)out_row = a | (b << 16);
+                        else if (st0) out_row[0] = __builtin_bit_cast(T, (unsigned short)a);
                     } else {
-                        const unsigned a = f32_to_raw16<T>(acc[done][0] * p.gain), b = f32_to_raw16<T>(acc[done][CPL - 1] * p.gain);
-                        if (ox + 1 < p.out_w && (((uintptr_t)(row + ox)) & 3) == 0) *(unsigned*)(row + ox) = a | (b << 16);
-                        else {
-                            if (ox < p.out_w) row[ox] = __builtin_bit_cast(T, (unsigned short)a);
-                            if (ox + 1 < p.out_w) row[ox + 1] = __builtin_bit_cast(T, (unsigned short)b);
-                        }
+                        if (st0) out_row[0] = __builtin_bit_cast(T, (unsigned short)a);
+                        if (st1) out_row[CPL - 1] = __builtin_bit_cast(T, (unsigned short)b);
                     }
                 }
             }
+            out_row += p.out_w; out_par ^= odd_pitch_out;
             #pragma unroll
             for (int q = 0; q < CPL; q++) acc[done][q] = 0.f;
         }
