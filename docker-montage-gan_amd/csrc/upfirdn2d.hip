@@ -317,33 +317,39 @@ __global__ void __launch_bounds__(256) upfirdn2d_stream(UfParams p, int nstrips,
     const int odd_pitch_out = p.out_w & 1;
     int out_par = (int)(((((uintptr_t)yout) >> 1) + (uint64_t)(uint32_t)((FH - 1) * odd_pitch_out)) & 1);   // parity of out_row's first element
 
-    for (int jb = 0; jb < rows_in; jb += GRP) {
-        // phase 1: issue the loads of GRP rows back to back
-        unsigned raw[GRP];
-        int par[GRP];
+    // Software pipeline: the loads of row group g+1 are in flight while group g is being consumed.
+    unsigned raw[GRP], raw_next[GRP];
+    int par[GRP], par_next[GRP];
+    int j_load = 0;                                                 // first row of the group the loader handles next
+    auto load_group = [&](unsigned (&dst)[GRP], int (&dpar)[GRP]) {
         #pragma unroll
         for (int r = 0; r < GRP; r++) {
-            raw[r] = 0; par[r] = 0;
-            const bool row_ok = (jb + r < rows_in) && iy >= 0 && iy < p.in_h;      // wave-uniform
+            dst[r] = 0; dpar[r] = 0;
+            const bool row_ok = (j_load + r < rows_in) && iy >= 0 && iy < p.in_h;      // wave-uniform
             if (row_ok) {
                 if constexpr (CPL == 1) {
-                    if (v0) raw[r] = __builtin_bit_cast(unsigned, (float)to_acc<T>(lane_in[e_row]));
+                    if (v0) dst[r] = __builtin_bit_cast(unsigned, (float)to_acc<T>(lane_in[e_row]));
                 } else {
                     // one aligned 4-byte access per lane: the pair that starts at the even element
                     // (e_row & ~1) + 2*lane; par = parity of the row start tells how it lines up with the columns
-                    par[r] = (int)(e_row & 1);
-                    const int64_t eb = e_row - par[r];
+                    dpar[r] = (int)(e_row & 1);
+                    const int64_t eb = e_row - dpar[r];
                     if (eb >= 0 && eb + 128 <= total_in) {          // wave-uniform: whole wave inside the tensor
-                        raw[r] = *(const unsigned*)(lane_in + eb);
+                        dst[r] = *(const unsigned*)(lane_in + eb);
                     } else {                                        // first / last row of the whole tensor
                         const int64_t E = eb + 2 * (int64_t)lane;
-                        if (E >= 0 && E < total_in) raw[r] = (unsigned)__builtin_bit_cast(unsigned short, xin[E]);
-                        if (E + 1 >= 0 && E + 1 < total_in) raw[r] |= (unsigned)__builtin_bit_cast(unsigned short, xin[E + 1]) << 16;
+                        if (E >= 0 && E < total_in) dst[r] = (unsigned)__builtin_bit_cast(unsigned short, xin[E]);
+                        if (E + 1 >= 0 && E + 1 < total_in) dst[r] |= (unsigned)__builtin_bit_cast(unsigned short, xin[E + 1]) << 16;
                     }
                 }
             }
             e_row += p.in_w; iy++;
         }
+        j_load += GRP;
+    };
+    load_group(raw, par);
+    for (int jb = 0; jb < rows_in; jb += GRP) {
+        if (jb + GRP < rows_in) load_group(raw_next, par_next);    // wave-uniform
         // phase 2 + 3 per row: line the pair up with the lane's columns, fetch the right-hand neighbours
         // by wave shuffle, accumulate the FH x FW taps into the ring, retire one output row
         #pragma unroll
@@ -393,6 +399,8 @@ __global__ void __launch_bounds__(256) upfirdn2d_stream(UfParams p, int nstrips,
             #pragma unroll
             for (int q = 0; q < CPL; q++) acc[done][q] = 0.f;
         }
+        #pragma unroll
+        for (int r = 0; r < GRP; r++) { raw[r] = raw_next[r]; par[r] = par_next[r]; }
     }
 }
 
