@@ -13,6 +13,7 @@
 //    structure (which taps hit non-zero samples) is resolved at compile time from
 //    the tile phase PX/PY, so an up=2 output costs (FW/2)*(FH/2) MACs.
 #include "mg_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -256,12 +257,14 @@ template <class T> __device__ __forceinline__ unsigned f32_to_raw16(float v) { r
 
 constexpr int US_FW = 4, US_FH = 4;
 
-template <class T, int RH>
+template <class T, int RH, int OWW>
 __global__ void __launch_bounds__(256) upfirdn2d_stream(UfParams p, int nstrips, int nchunks, uint32_t ntasks)
 {
     constexpr int CPL = StreamTraits<T>::CPL;
     constexpr int FW = US_FW, FH = US_FH;
-    constexpr int OWW = (64 * CPL - (FW - 1)) & ~(CPL - 1);       // outputs per strip (even for CPL = 2)
+    constexpr int ES = (int)sizeof(T);
+    constexpr unsigned BAD = 0x80000000u;                           // a byte offset no tensor reaches (sizes < 2^31 bytes)
+    static_assert(OWW <= 64 * CPL - (FW - 1) && OWW % CPL == 0, "strip too wide");
     constexpr int GRP = 2 * FH;                                     // input rows in flight per wave
     const int lane = threadIdx.x & 63;
     const uint32_t task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
@@ -279,30 +282,40 @@ __global__ void __launch_bounds__(256) upfirdn2d_stream(UfParams p, int nstrips,
             ft[ky][kx] = v * p.gain;                                // fold the gain into the taps
         }
 
+    // Buffer descriptors over the WHOLE tensors: every access is range checked by the hardware (out-of-range
+    // loads read 0, out-of-range stores are dropped), so the inner loop has no bounds branches at all.
+    const uint32_t in_bytes = (uint32_t)(((int64_t)p.n * p.c * p.in_h * p.in_w * ES + 3) & ~3ll);
+    const uint32_t out_bytes = (uint32_t)((int64_t)p.n * p.c * p.out_h * p.out_w * ES);
+    const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)in_bytes, 0x00020000);
+    const auto rout = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)out_bytes, 0x00020000);
+
     // wave-uniform geometry (up = down = 1: first input sample of output o is o - pad0)
     const int out_x0 = strip * OWW, out_y0 = chunk * RH;
     const int in_x0 = out_x0 - p.padx0, in_y0 = out_y0 - p.pady0;
     const int rows_out = min(RH, p.out_h - out_y0), rows_in = rows_out + FH - 1;
-    const int64_t total_in = (int64_t)p.n * p.c * p.in_h * p.in_w;
-    const int64_t e_first = (int64_t)plane * p.in_h * p.in_w + (int64_t)in_y0 * p.in_w + in_x0;   // element (row 0 of the strip, col in_x0)
-    const T* __restrict__ xin = (const T*)p.x;
-    T* __restrict__ yout = (T*)p.y + (int64_t)plane * p.out_h * p.out_w + (int64_t)out_y0 * p.out_w + out_x0;
+    const int in_pitch = p.in_w * ES, out_pitch = p.out_w * ES;
+    // byte offset of (input row in_y0 + j, column in_x0) and of (output row out_y0 + j - (FH-1), column out_x0)
+    int in_off = (int)(((int64_t)plane * p.in_h + in_y0) * p.in_w + in_x0) * ES;
+    int out_off = (int)(((int64_t)plane * p.out_h + out_y0 - (FH - 1)) * p.out_w + out_x0) * ES;
+    int iy = in_y0;
 
     // per-lane invariants
     const int col0 = in_x0 + lane * CPL;
     const bool v0 = col0 >= 0 && col0 < p.in_w;
     const bool v1 = col0 + 1 >= 0 && col0 + 1 < p.in_w;
-    const int oxl = lane * CPL;                                     // output column inside the strip
+    const bool vm1 = col0 - 1 >= 0 && col0 - 1 < p.in_w;
+    const int oxl = lane * CPL;
     const bool st0 = oxl < OWW && out_x0 + oxl < p.out_w;
     const bool st1 = oxl + 1 < OWW && out_x0 + oxl + 1 < p.out_w;
-    const T* lane_in = xin + lane * CPL;
-    T* lane_out = yout + oxl;
-    // 16-bit pairs: which halves of the lane's aligned pair are inside the image, for an even (M0) and an
-    // odd (M1: the pair starts one column to the left) row start.  Masking at the source means the
-    // neighbours' values arrive already zeroed through the shuffles.
-    const bool vm1 = col0 - 1 >= 0 && col0 - 1 < p.in_w;
+    const unsigned lane_in = (unsigned)(lane * CPL * ES);
+    // 16-bit pairs: which halves of the lane's aligned pair lie inside the image for an even (M0) / odd (M1) row start
     const unsigned M0 = (v0 ? 0xffffu : 0u) | (v1 ? 0xffff0000u : 0u);
     const unsigned M1 = (vm1 ? 0xffffu : 0u) | (v0 ? 0xffff0000u : 0u);
+    // store offsets inside the row; BAD drops the lane
+    const unsigned so_a = (CPL == 1 ? st0 : (st0 && st1)) ? (unsigned)(oxl * ES) : BAD;      // full-width store
+    const unsigned so_e0 = (CPL == 2 && st0 && !st1) ? (unsigned)(oxl * ES) : BAD;            // 16-bit edge lane (aligned rows)
+    const unsigned so_h0 = st0 ? (unsigned)(oxl * ES) : BAD, so_h1 = st1 ? (unsigned)((oxl + 1) * ES) : BAD;   // misaligned rows
+    const bool any_edge = __builtin_amdgcn_readfirstlane(__ballot(so_e0 != BAD) != 0);
 
     float acc[FH][CPL];
     #pragma unroll
@@ -310,55 +323,39 @@ __global__ void __launch_bounds__(256) upfirdn2d_stream(UfParams p, int nstrips,
         #pragma unroll
         for (int q = 0; q < CPL; q++) acc[a][q] = 0.f;
 
-    // wave-uniform running state, advanced by one row per step (no per-row multiplications)
-    int64_t e_row = e_first;                                        // element offset of (input row j, column in_x0)
-    int iy = in_y0;
-    T* out_row = lane_out - (int64_t)(FH - 1) * p.out_w;            // row j - (FH-1)
-    const int odd_pitch_out = p.out_w & 1;
-    int out_par = (int)(((((uintptr_t)yout) >> 1) + (uint64_t)(uint32_t)((FH - 1) * odd_pitch_out)) & 1);   // parity of out_row's first element
-
     // Software pipeline: the loads of row group g+1 are in flight while group g is being consumed.
     unsigned raw[GRP], raw_next[GRP];
     int par[GRP], par_next[GRP];
-    int j_load = 0;                                                 // first row of the group the loader handles next
+    int j_load = 0;
     auto load_group = [&](unsigned (&dst)[GRP], int (&dpar)[GRP]) {
         #pragma unroll
         for (int r = 0; r < GRP; r++) {
-            dst[r] = 0; dpar[r] = 0;
             const bool row_ok = (j_load + r < rows_in) && iy >= 0 && iy < p.in_h;      // wave-uniform
-            if (row_ok) {
-                if constexpr (CPL == 1) {
-                    if (v0) dst[r] = __builtin_bit_cast(unsigned, (float)to_acc<T>(lane_in[e_row]));
-                } else {
-                    // one aligned 4-byte access per lane: the pair that starts at the even element
-                    // (e_row & ~1) + 2*lane; par = parity of the row start tells how it lines up with the columns
-                    dpar[r] = (int)(e_row & 1);
-                    const int64_t eb = e_row - dpar[r];
-                    if (eb >= 0 && eb + 128 <= total_in) {          // wave-uniform: whole wave inside the tensor
-                        dst[r] = *(const unsigned*)(lane_in + eb);
-                    } else {                                        // first / last row of the whole tensor
-                        const int64_t E = eb + 2 * (int64_t)lane;
-                        if (E >= 0 && E < total_in) dst[r] = (unsigned)__builtin_bit_cast(unsigned short, xin[E]);
-                        if (E + 1 >= 0 && E + 1 < total_in) dst[r] |= (unsigned)__builtin_bit_cast(unsigned short, xin[E + 1]) << 16;
-                    }
-                }
+            if constexpr (CPL == 1) {
+                dpar[r] = 0;
+                const unsigned ro = row_ok ? (unsigned)in_off : BAD;
+                dst[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, lane_in + ro, 0, 0);
+            } else {
+                // one aligned 4-byte access per lane: the pair starting at the even element below the row start;
+                // par = parity of the row start tells how the pair lines up with the lane's columns
+                dpar[r] = (in_off >> 1) & 1;
+                const unsigned ro = row_ok ? (unsigned)(in_off & ~3) : BAD;
+                dst[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, lane_in + ro, 0, 0);
             }
-            e_row += p.in_w; iy++;
+            in_off += in_pitch; iy++;
         }
         j_load += GRP;
     };
     load_group(raw, par);
     for (int jb = 0; jb < rows_in; jb += GRP) {
         if (jb + GRP < rows_in) load_group(raw_next, par_next);    // wave-uniform
-        // phase 2 + 3 per row: line the pair up with the lane's columns, fetch the right-hand neighbours
-        // by wave shuffle, accumulate the FH x FW taps into the ring, retire one output row
         #pragma unroll
         for (int r = 0; r < GRP; r++) {
             const int j = jb + r;
             if (j >= rows_in) break;                                // wave-uniform
             float v[CPL + FW - 1];
             if constexpr (CPL == 1) {
-                v[0] = __builtin_bit_cast(float, raw[r]);
+                v[0] = v0 ? __builtin_bit_cast(float, raw[r]) : 0.f;
                 #pragma unroll
                 for (int k = 1; k < FW; k++) v[k] = __shfl_down(v[0], k, 64);
             } else {
@@ -383,19 +380,20 @@ __global__ void __launch_bounds__(256) upfirdn2d_stream(UfParams p, int nstrips,
             const int done = (r + 1) % FH;
             if (j >= FH - 1) {                                      // wave-uniform
                 if constexpr (CPL == 1) {
-                    if (st0) out_row[0] = from_acc<T>(acc[done][0]);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)to_acc<T>(from_acc<T>(acc[done][0]))), rout,
+                                                          so_a + (unsigned)out_off, 0, 0);
                 } else {
                     const unsigned a = f32_to_raw16<T>(acc[done][0]), b = f32_to_raw16<T>(acc[done][CPL - 1]);
-                    if (out_par == 0) {                             // wave-uniform: 4-byte aligned row start
-                        if (st1) *(unsigned*)out_row = a | (b << 16);
-                        else if (st0) out_row[0] = __builtin_bit_cast(T, (unsigned short)a);
+                    if ((out_off & 3) == 0) {                       // wave-uniform: 4-byte aligned row start
+                        __builtin_amdgcn_raw_buffer_store_b32(a | (b << 16), rout, so_a + (unsigned)out_off, 0, 0);
+                        if (any_edge) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)a, rout, so_e0 + (unsigned)out_off, 0, 0);
                     } else {
-                        if (st0) out_row[0] = __builtin_bit_cast(T, (unsigned short)a);
-                        if (st1) out_row[CPL - 1] = __builtin_bit_cast(T, (unsigned short)b);
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)a, rout, so_h0 + (unsigned)out_off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)b, rout, so_h1 + (unsigned)out_off, 0, 0);
                     }
                 }
             }
-            out_row += p.out_w; out_par ^= odd_pitch_out;
+            out_off += out_pitch;
             #pragma unroll
             for (int q = 0; q < CPL; q++) acc[done][q] = 0.f;
         }
@@ -408,15 +406,23 @@ template <class T>
 bool try_stream(const UfParams& p, hipStream_t s)
 {
     constexpr int CPL = StreamTraits<T>::CPL;
-    constexpr int OWW = (64 * CPL - (US_FW - 1)) & ~(CPL - 1);
+    // outputs per strip: a whole number of 128-byte lines, so that neighbouring waves (which may sit on
+    // different XCDs with non-coherent L2s) never write parts of the same line
+    static int oww_env = getenv("MG_STREAM_OWW") ? atoi(getenv("MG_STREAM_OWW")) : 0;
+    constexpr int OWW_WIDE = (64 * CPL - (US_FW - 1)) & ~(CPL - 1), OWW_LINE = 128 / (int)sizeof(T) * (CPL == 1 ? 1 : 1);
+    const bool wide = (oww_env != 2);
+    const int OWW = wide ? OWW_WIDE : OWW_LINE;
     constexpr int RH = 64;
     if (!(p.upx == 1 && p.upy == 1 && p.downx == 1 && p.downy == 1 && p.f_w <= US_FW && p.f_h <= US_FH)) return false;
     if (p.out_w < 48) return false;                                 // small planes: the tiled kernel packs several per workgroup
+    if ((int64_t)p.n * p.c * p.in_h * p.in_w * (int64_t)sizeof(T) >= (1ll << 31) - 8 || (int64_t)p.n * p.c * p.out_h * p.out_w * (int64_t)sizeof(T) >= (1ll << 31) - 8)
+        return false;                                               // 32-bit buffer offsets
     int nstrips = (p.out_w + OWW - 1) / OWW, nchunks = (p.out_h + RH - 1) / RH;
     int64_t ntasks = (int64_t)nstrips * nchunks * p.n * p.c;
     if (ntasks > (int64_t)UINT32_MAX / 2) return false;
     uint32_t blocks = (uint32_t)((ntasks + 3) / 4);
-    hipLaunchKernelGGL((upfirdn2d_stream<T, RH>), dim3(blocks), dim3(256), 0, s, p, nstrips, nchunks, (uint32_t)ntasks);
+    if (wide) hipLaunchKernelGGL((upfirdn2d_stream<T, RH, OWW_WIDE>), dim3(blocks), dim3(256), 0, s, p, nstrips, nchunks, (uint32_t)ntasks);
+    else      hipLaunchKernelGGL((upfirdn2d_stream<T, RH, OWW_LINE>), dim3(blocks), dim3(256), 0, s, p, nstrips, nchunks, (uint32_t)ntasks);
     return true;
 }
 
