@@ -140,7 +140,7 @@ def main():
     ap.add_argument('--marker-file', default=None, help='write clock readings at the start/end of the timed region (for cutting a rocprofv3 trace)')
     args = ap.parse_args()
     if args.batch_gpu is None:
-        args.batch_gpu = 8 if args.workload == 'aio' else 32
+        args.batch_gpu = 32
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
