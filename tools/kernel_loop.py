@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Launch ONE native kernel configuration a few times (for rocprofv3 --pmc runs).
+usage: kernel_loop.py <upfirdn2d|bias_act|epilogue> <dtype> [iters]"""
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = 'docker-montage-gan_amd'
+importlib.import_module(PKG)
+U = importlib.import_module(f'{PKG}.torch_utils.ops.upfirdn2d')
+B = importlib.import_module(f'{PKG}.torch_utils.ops.bias_act')
+E = importlib.import_module(f'{PKG}.torch_utils.ops.modconv_epilogue')
+which, dt = sys.argv[1], getattr(torch, sys.argv[2])
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+dev = torch.device('cuda', 0)
+n, c, r = 32, 64, 256
+f = U.setup_filter([1, 3, 3, 1]).to(dev)
+if which == 'upfirdn2d':
+    x = torch.randn([n, c, r + 1, r + 1], device=dev).to(dt)
+    fn = lambda: U.upfirdn2d(x, f, padding=[1, 1, 1, 1], gain=4)
+elif which == 'bias_act':
+    x = torch.randn([n, c, r, r], device=dev).to(dt)
+    b = torch.randn([c], device=dev).to(dt)
+    fn = lambda: B.bias_act(x, b, act='lrelu', clamp=256)
+else:
+    x = torch.randn([n, c, r, r], device=dev).to(dt)
+    d = torch.rand([n, c], device=dev) + 0.5
+    nz = torch.randn([r, r], device=dev)
+    b = torch.randn([c], device=dev)
+    fn = lambda: E.modconv_epilogue(x, d, nz, b, act='lrelu', clamp=256)
+with torch.no_grad():
+    for _ in range(iters):
+        fn()
+torch.cuda.synchronize()
+print('algorithmic bytes per launch:', (x.numel() + fn().numel()) * x.element_size())
