@@ -26,6 +26,12 @@ elif which == 'bias_act':
     x = torch.randn([n, c, r, r], device=dev).to(dt)
     b = torch.randn([c], device=dev).to(dt)
     fn = lambda: B.bias_act(x, b, act='lrelu', clamp=256)
+elif which == 'calib4':
+    # known byte count through 4-byte-per-lane loads: a float32 view that is not 16-byte aligned makes
+    # bias_act take its VEC=1 path (one dword per lane per access)
+    base = torch.randn([n * c * r * r + 1], device=dev)
+    x = base[1:].reshape(n, c, r, r)
+    fn = lambda: B.bias_act(x, None, act='lrelu')
 else:
     x = torch.randn([n, c, r, r], device=dev).to(dt)
     d = torch.rand([n, c], device=dev) + 0.5
