@@ -216,8 +216,18 @@ def main():
             total_ms = sum(v['ms'] for v in rec.values())
             name, top = max(rec.items(), key=lambda kv: kv[1]['ms'])
             achieved = top['bytes'] / (top['ms'] * 1e-3) / 1e9
+            # HBM traffic: PMC counters cannot be read from inside this process; profiles/r01_pmc_traffic.json holds the
+            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement (separate passes, calibrated) of this kernel on its
+            # dominant shape as a ratio to the algorithmic bytes; applied here to this run's bytes per launch.
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels'].get(name)
+                if pmc:
+                    traffic = round(pmc['traffic_over_algorithmic'] * top['bytes'] / top['launches'])
+            except Exception:
+                pass
             roofline = dict(bound='hbm', kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
-                            frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=None,
+                            frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
                             launches_per_step=round(top['launches'] / args.prof_steps, 1),
                             avg_launch_us=round(top['ms'] * 1e3 / top['launches'], 2),
                             algorithmic_bytes_per_launch=round(top['bytes'] / top['launches']),
