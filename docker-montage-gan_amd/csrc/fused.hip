@@ -15,6 +15,7 @@ namespace {
 template <class T> struct FbArgs {
     const T* x; const float* d; const float* noise; const T* b; T* y; T* y2;
     float alpha, gain, clamp, noise_gain;
+    const float* noise_gain_dev;
     int64_t noise_stride_n;
     uint32_t c, hw, total_vec;
     FastDiv hwv_div, c_div;     // hw/VEC and C
@@ -31,6 +32,7 @@ __global__ void __launch_bounds__(256) fma_bias_act_fwd_kernel(FbArgs<T> p)
     struct alignas(VEC >= 4 ? 16 : 4) NV { float v[VEC]; };
     const BaConst<float> k = {p.alpha, p.gain, p.clamp};
     const uint32_t hwv = p.hw / VEC;
+    const float ngain = p.noise_gain * ((p.noise && p.noise_gain_dev) ? *p.noise_gain_dev : 1.f);
     const bool nz_vec = (VEC == 1) || ((((uintptr_t)p.noise) & 15) == 0 && ((p.noise_stride_n * 4) & 15) == 0);
     for (uint32_t base = blockIdx.x * (256u * FB_U); base < p.total_vec; base += gridDim.x * (256u * FB_U)) {
         V xin[FB_U];
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(256) fma_bias_act_fwd_kernel(FbArgs<T> p)
             #pragma unroll
             for (int e = 0; e < VEC; e++) {
                 float v = to_acc<T>(xin[u].v[e]) * dc;
-                if (p.noise) v += nzv[u].v[e] * p.noise_gain;
+                if (p.noise) v += nzv[u].v[e] * ngain;
                 // the reference rounds the fma result to T before bias_act reads it back
                 v = to_acc<T>(from_acc<T>(v));
                 out.v[e] = from_acc<T>(ba_eval<float, A>(0, v, bb, 0.f, 0.f, 1.f, k));
@@ -229,10 +231,95 @@ __global__ void __launch_bounds__(256) filtered_lrelu_kernel(FlArgs p)
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Backward with fused reductions (mg_bwd_fused).  One workgroup = one slice of one (n,c) plane, so the
+// three sums it owns are a wave-shuffle + LDS reduction followed by ONE float atomic each.
+template <class T> struct BrArgs {
+    const T* dy; const T* yref; const T* x; const float* d; const float* noise; T* dx;
+    float* gd; float* gb; float* gs;
+    float alpha, gain, clamp;
+    int64_t noise_stride_n;
+    uint32_t c, hw, slices, slice_len;      // slice_len: elements per slice, a multiple of 256*VEC
+};
+
+template <class T, int A, int VEC>
+__global__ void __launch_bounds__(256) bwd_fused_kernel(BrArgs<T> p)
+{
+    struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
+    const BaConst<float> k = {p.alpha, p.gain, p.clamp};
+    const uint32_t plane = blockIdx.x / p.slices, slice = blockIdx.x - plane * p.slices;
+    const uint32_t n = plane / p.c, ch = plane - n * p.c;
+    const size_t base = (size_t)plane * p.hw;
+    const uint32_t lo = slice * p.slice_len, hi = min(p.hw, lo + p.slice_len);
+    const float dc = p.d ? p.d[plane] : 1.f;
+    const float* nz = p.noise ? p.noise + (int64_t)n * p.noise_stride_n : nullptr;
+    float s_gd = 0.f, s_gb = 0.f, s_gs = 0.f;
+    for (uint32_t i = lo + threadIdx.x * VEC; i < hi; i += 256u * VEC) {
+        // hw % VEC == 0 on the vector path, so a vector never crosses the end of the plane
+        V vdy = *(const V*)(p.dy + base + i), vy, vx, out;
+        if (p.yref) vy = *(const V*)(p.yref + base + i);
+        if (p.x) vx = *(const V*)(p.x + base + i);
+        #pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            float g = to_acc<T>(vdy.v[e]);
+            if (p.yref) g = ba_eval<float, A>(1, g, 0.f, 0.f, to_acc<T>(vy.v[e]), 1.f, k);
+            const float gq = to_acc<T>(from_acc<T>(g));            // autograd materialises dpre in T
+            out.v[e] = from_acc<T>(gq * dc);
+            s_gb += gq;
+            if (p.x) s_gd += gq * to_acc<T>(vx.v[e]);
+            if (nz) s_gs += gq * nz[i + e];
+        }
+        *(V*)(p.dx + base + i) = out;
+    }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s_gd += __shfl_down(s_gd, o, 64); s_gb += __shfl_down(s_gb, o, 64); s_gs += __shfl_down(s_gs, o, 64);
+    }
+    __shared__ float red[3][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wv] = s_gd; red[1][wv] = s_gb; red[2][wv] = s_gs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (p.gd) atomicAdd(p.gd + plane, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        if (p.gb) atomicAdd(p.gb + ch, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        if (p.gs) atomicAdd(p.gs, red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+    }
+}
+
+template <class T, int A>
+void launch_br(BrArgs<T> p, bool wide, uint32_t planes, hipStream_t s)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    const uint32_t vec = wide ? VEC : 1;
+    const uint32_t unit = 256u * vec;
+    uint32_t slices = (p.hw + unit * 8 - 1) / (unit * 8);          // about 8 vectors per lane per slice
+    if (slices < 1) slices = 1;
+    if (slices > 64) slices = 64;
+    uint32_t len = (p.hw + slices - 1) / slices;
+    len = (len + unit - 1) / unit * unit;
+    slices = (p.hw + len - 1) / len;
+    p.slices = slices; p.slice_len = len;
+    if (wide) hipLaunchKernelGGL((bwd_fused_kernel<T, A, VEC>), dim3(planes * slices), dim3(256), 0, s, p);
+    else      hipLaunchKernelGGL((bwd_fused_kernel<T, A, 1>), dim3(planes * slices), dim3(256), 0, s, p);
+}
+
+template <class T>
+int dispatch_br(const BrArgs<T>& p, int act, bool wide, uint32_t planes, hipStream_t s)
+{
+    switch (act) {
+    case 1: launch_br<T, 1>(p, wide, planes, s); return MG_OK;
+    case 2: launch_br<T, 2>(p, wide, planes, s); return MG_OK;
+    case 3: launch_br<T, 3>(p, wide, planes, s); return MG_OK;
+    }
+    mg_set_error("bwd_fused: only linear / relu / lrelu are fused (activation %d)", act);
+    return MG_E_ARG;
+}
+
 } // namespace
 
 extern "C" int mg_fma_bias_act(const void* x, const float* d, const float* noise, const void* b, void* y, int dtype,
-                               int act, float alpha, float gain, float clamp, float noise_gain,
+                               int act, float alpha, float gain, float clamp, float noise_gain, const float* noise_gain_dev,
                                int64_t noise_stride_n, int32_t n, int32_t c, int32_t hw, void* stream)
 {
     MG_REQUIRE(x && y, "x must reside on the device");
@@ -250,7 +337,7 @@ extern "C" int mg_fma_bias_act(const void* x, const float* d, const float* noise
         if (sizeof(T) == 8) break;
         FbArgs<T> p;
         p.x = (const T*)x; p.d = d; p.noise = noise; p.b = (const T*)b; p.y = (T*)y; p.y2 = nullptr;
-        p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_gain = noise_gain; p.noise_stride_n = noise_stride_n;
+        p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_gain = noise_gain; p.noise_gain_dev = noise_gain_dev; p.noise_stride_n = noise_stride_n;
         p.c = (uint32_t)c; p.hw = (uint32_t)hw; p.total_vec = (uint32_t)total; p.c_div = make_fastdiv((uint32_t)c);
         rc = dispatch_fb<T>(p, act, false, wide, s);
     });
@@ -277,7 +364,7 @@ extern "C" int mg_fma_bias_act_bwd(const void* dy, const void* yref, const float
         if (sizeof(T) == 8) break;
         FbArgs<T> p;
         p.x = (const T*)dy; p.d = d; p.noise = nullptr; p.b = (const T*)yref; p.y = (T*)dx; p.y2 = (T*)dpre;
-        p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_gain = 0.f; p.noise_stride_n = 0;
+        p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_gain = 0.f; p.noise_gain_dev = nullptr; p.noise_stride_n = 0;
         p.c = (uint32_t)c; p.hw = (uint32_t)hw; p.total_vec = (uint32_t)total; p.c_div = make_fastdiv((uint32_t)c);
         rc = dispatch_fb<T>(p, act, true, wide, s);
     });
@@ -321,4 +408,34 @@ extern "C" int mg_filtered_lrelu(const void* x, const void* b, const float* fu, 
         hipLaunchKernelGGL((filtered_lrelu_kernel<T>), dim3((uint32_t)blocks), dim3(256), lds, s, p);
     });
     return mg_check_launch(MG_K_FILTERED_LRELU, "filtered_lrelu");
+}
+
+extern "C" int mg_bwd_fused(const void* dy, const void* yref, const void* x, const float* d, const float* noise,
+                            void* dx, float* gd, float* gb, float* gs, int dtype, int act, float alpha, float gain,
+                            float clamp, int64_t noise_stride_n, int32_t n, int32_t c, int32_t hw, void* stream)
+{
+    MG_REQUIRE(dy && dx, "dy must reside on the device");
+    MG_REQUIRE(dtype == MG_F32 || dtype == MG_F16 || dtype == MG_BF16, "bwd_fused: unsupported dtype %d", dtype);
+    MG_REQUIRE(n >= 0 && c >= 1 && hw >= 1, "bwd_fused: bad shape");
+    MG_REQUIRE(!gd || x, "bwd_fused: gd needs x");
+    MG_REQUIRE(!gs || noise, "bwd_fused: gs needs noise");
+    int64_t total = (int64_t)n * c * hw;
+    MG_REQUIRE(total <= INT32_MAX, "x is too large");
+    if (total == 0) return MG_OK;
+    int es = mg_dtype_size(dtype), vec = 16 / es;
+    bool wide = (hw % vec == 0) && ((((uintptr_t)dy | (uintptr_t)yref | (uintptr_t)x | (uintptr_t)dx) & 15) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    int passes = 2 + (yref != nullptr) + (x != nullptr);
+    MgLaunchScope scope(MG_K_BWD_FUSED, s, (double)passes * total * es);
+    int rc = MG_OK;
+    MG_DISPATCH_DTYPE(dtype, {
+        if (sizeof(T) == 8) break;
+        BrArgs<T> p;
+        p.dy = (const T*)dy; p.yref = (const T*)yref; p.x = (const T*)x; p.d = d; p.noise = gs ? noise : nullptr; p.dx = (T*)dx;
+        p.gd = gd; p.gb = gb; p.gs = gs; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_stride_n = noise_stride_n;
+        p.c = (uint32_t)c; p.hw = (uint32_t)hw; p.slices = 1; p.slice_len = (uint32_t)hw;
+        rc = dispatch_br<T>(p, act, wide, (uint32_t)(n * c), s);
+    });
+    if (rc) return rc;
+    return mg_check_launch(MG_K_BWD_FUSED, "bwd_fused");
 }

@@ -17,10 +17,10 @@ LIB_PATH = os.environ.get('MONTAGE_HIP_LIB', os.path.join(CSRC, 'libmontage_hip.
 MG_F32, MG_F16, MG_BF16, MG_F64 = 0, 1, 2, 3
 K_UPFIRDN2D_GENERIC, K_UPFIRDN2D_TILED, K_BIAS_ACT, K_FMA_BIAS_ACT = 0, 1, 2, 3
 K_ALPHA_COMPOSITE_FWD, K_ALPHA_COMPOSITE_BWD, K_TRANSLATE_FWD, K_TRANSLATE_BWD_INPUT = 4, 5, 6, 7
-K_TRANSLATE_BWD_SHIFT, K_FILTERED_LRELU = 8, 9
+K_TRANSLATE_BWD_SHIFT, K_FILTERED_LRELU, K_BWD_FUSED = 8, 9, 10
 KERNEL_NAMES = {0: 'upfirdn2d_generic', 1: 'upfirdn2d_tiled', 2: 'bias_act', 3: 'fma_bias_act', 4: 'alpha_composite_fwd',
                 5: 'alpha_composite_bwd', 6: 'translate_fwd', 7: 'translate_bwd_input', 8: 'translate_bwd_shift',
-                9: 'filtered_lrelu'}
+                9: 'filtered_lrelu', 10: 'bwd_fused'}
 
 _lib = None
 _lock = threading.Lock()
@@ -50,9 +50,10 @@ def _declare(L):
     L.mg_bias_act.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                               c_float, c_float, c_float, c_i64, c_i32, c_i64, c_void_p]
     L.mg_fma_bias_act.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
-                                  c_float, c_float, c_i64, c_i32, c_i32, c_i32, c_void_p]
+                                  c_float, c_float, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p]
     L.mg_fma_bias_act_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
                                       c_float, c_i32, c_i32, c_i32, c_void_p]
+    L.mg_bwd_fused.argtypes = [c_void_p] * 9 + [c_int, c_int, c_float, c_float, c_float, c_i64, c_i32, c_i32, c_i32, c_void_p]
     L.mg_alpha_composite_fwd.argtypes = [c_void_p, c_void_p, c_int, c_i32, c_i32, c_i32, c_i32, c_void_p]
     L.mg_alpha_composite_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_i32, c_i32, c_i32, c_i32, c_int, c_void_p]
     L.mg_translate_sample_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_i32, c_i32, c_i32, c_i32, c_float, c_void_p]
@@ -63,7 +64,7 @@ def _declare(L):
                                    [c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p]
     for name in ('mg_upfirdn2d', 'mg_upfirdn2d_index_table', 'mg_bias_act', 'mg_fma_bias_act', 'mg_fma_bias_act_bwd',
                  'mg_alpha_composite_fwd', 'mg_alpha_composite_bwd', 'mg_translate_sample_fwd',
-                 'mg_translate_sample_bwd_input', 'mg_translate_sample_bwd_shift', 'mg_filtered_lrelu',
+                 'mg_translate_sample_bwd_input', 'mg_translate_sample_bwd_shift', 'mg_filtered_lrelu', 'mg_bwd_fused',
                  'mg_prof_enable', 'mg_prof_collect', 'mg_prof_reset'):
         getattr(L, name).restype = c_int
 

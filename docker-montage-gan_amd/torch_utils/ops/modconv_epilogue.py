@@ -15,6 +15,12 @@ the fused native gradient kernel; under ``create_graph=True`` (path-length regul
 differentiates the generator twice) the backward is assembled from ops that are themselves
 differentiable (the native bias_act gradient Function + aten products/reductions), so gradients
 of any order the underlying ops support are available.
+
+The first-order backward is ONE kernel too (``mg_bwd_fused``): it reads dy, y and the convolution
+output x once, writes dx, and leaves sum(dpre*x) per (n,c), sum(dpre) per channel and
+sum(dpre*noise_raw) in float32 accumulators -- the gradients of dcoefs, bias and noise_strength that
+autograd would otherwise produce with five more passes over the activation.  ``channel_scale`` is the
+same machinery for the modulation ``x * styles[N,C,1,1]`` that precedes the convolution.
 """
 import torch
 
@@ -49,73 +55,99 @@ def _epilogue_hip(act, alpha, gain, clamp):
     null = _ba._null_tensor
 
     class ModconvEpilogue(torch.autograd.Function):
+        """inputs: x, dcoefs, noise (scaled, or raw when `strength` is given), strength (0-dim or None), b"""
+
         @staticmethod
-        def forward(ctx, x, dcoefs, noise, b):
+        def forward(ctx, x, dcoefs, noise, strength, b):
             n, c, h, w = x.shape
             x = x.contiguous()
-            d32 = dcoefs.detach().to(torch.float32).contiguous() if dcoefs is not None else None
-            nz32, nz_stride = None, 0
+            # the reference multiplies by dcoefs.to(x.dtype): keep that rounding, then widen for the kernel
+            d32 = dcoefs.detach().to(x.dtype).to(torch.float32).contiguous() if dcoefs is not None else None
+            nz32, nz_stride, s32 = None, 0, None
             if noise is not None:
                 assert noise.numel() in (h * w, n * h * w), 'noise must be [H,W] or [N,1,H,W]'
                 nz32 = noise.detach().to(torch.float32).contiguous()
                 nz_stride = h * w if noise.numel() == n * h * w and n > 1 else 0
+                if strength is not None:        # stays on the device: the kernel reads the scalar itself
+                    s32 = strength.detach().to(torch.float32).reshape(1).contiguous()
             bb = b.detach().to(x.dtype).contiguous() if b is not None else None
             y = torch.empty_like(x)
             if x.numel():
                 with torch.cuda.device(x.device):
                     native.check(native.lib().mg_fma_bias_act(
                         native.ptr(x), native.ptr(d32), native.ptr(nz32), native.ptr(bb), native.ptr(y),
-                        native.dtype_code(x.dtype), idx, alpha, gain, clamp, 1.0, nz_stride, n, c, h * w,
+                        native.dtype_code(x.dtype), idx, alpha, gain, clamp, 1.0, native.ptr(s32), nz_stride, n, c, h * w,
                         native.stream_ptr(x.device)))
-            ctx.save_for_backward(x, dcoefs if dcoefs is not None else null, y)
-            ctx.has = (dcoefs is not None, noise is not None, b is not None)
-            ctx.noise_meta = None if noise is None else (noise.dtype, noise.shape)
+            ctx.save_for_backward(x, dcoefs if dcoefs is not None else null, y, nz32 if nz32 is not None else null,
+                                  s32 if s32 is not None else null)
+            ctx.has = (dcoefs is not None, noise is not None, b is not None, strength is not None)
+            ctx.noise_meta = None if noise is None else (noise.dtype, noise.shape, nz_stride)
             ctx.b_dtype = None if b is None else b.dtype
+            ctx.s_dtype = None if strength is None else strength.dtype
             return y
 
         @staticmethod
         def backward(ctx, dy):
-            x, dcoefs, y = ctx.saved_tensors
+            x, dcoefs, y, nz32, s32 = ctx.saved_tensors
             n, c, h, w = x.shape
-            has_d, has_nz, has_b = ctx.has
-            need = ctx.needs_input_grad
+            has_d, has_nz, has_b, has_s = ctx.has
+            nz_gain = s32.reshape([]) if has_s else 1.0
+            need = ctx.needs_input_grad          # x, dcoefs, noise, strength, b
             dy = dy.contiguous()
+            ident = (act == 'linear' and gain == 1 and clamp < 0)
             if torch.is_grad_enabled():
                 # differentiable assembly (create_graph=True)
-                dpre = grad_fn.apply(dy, null, null, y) if not (act == 'linear' and gain == 1 and clamp < 0) else dy
+                dpre = dy if ident else grad_fn.apply(dy, null, null, y)
                 dx = dpre * dcoefs.to(dpre.dtype).reshape(n, c, 1, 1) if has_d else dpre
-            else:
-                want_pre = has_d and (need[1] or (has_nz and need[2]) or (has_b and need[3]))
-                dx = torch.empty_like(x)
-                dpre = torch.empty_like(x) if want_pre else None
-                d32 = dcoefs.to(torch.float32).contiguous() if has_d else None
-                if x.numel():
-                    with torch.cuda.device(x.device):
-                        native.check(native.lib().mg_fma_bias_act_bwd(
-                            native.ptr(dy), native.ptr(y), native.ptr(d32), native.ptr(dx), native.ptr(dpre),
-                            native.dtype_code(x.dtype), idx, alpha, gain, clamp, n, c, h * w, native.stream_ptr(x.device)))
-                if dpre is None:
-                    dpre = dx                  # without dcoefs, dx IS the pre-activation gradient
-            gd = gn = gb = None
-            if has_d and need[1]:
-                gd = (dpre * x).sum(dim=[2, 3]).to(dcoefs.dtype)
-            if has_nz and need[2]:
-                dt, shp = ctx.noise_meta
-                per_sample = len(shp) == 4 and shp[0] == n and n > 1
-                gn = (dpre.sum(dim=1, keepdim=True) if per_sample else dpre.sum(dim=[0, 1])).reshape(shp).to(dt)
-            if has_b and need[3]:
-                gb = dpre.sum(dim=[0, 2, 3]).to(ctx.b_dtype)
-            return (dx if need[0] else None), gd, gn, gb
+                gd = (dpre * x).sum(dim=[2, 3]).to(dcoefs.dtype) if has_d and need[1] else None
+                gn = gs = None
+                if has_nz and (need[2] or (has_s and need[3])):
+                    dt, shp, stride = ctx.noise_meta
+                    per_sample = stride != 0
+                    gnoise = (dpre.sum(dim=1, keepdim=True) if per_sample else dpre.sum(dim=[0, 1])).reshape(shp)
+                    if need[2]:
+                        gn = (gnoise * nz_gain).to(dt)
+                    if has_s and need[3]:
+                        gs = (gnoise.to(torch.float32) * nz32.reshape(shp)).sum().to(ctx.s_dtype)
+                gb = dpre.sum(dim=[0, 2, 3]).to(ctx.b_dtype) if has_b and need[4] else None
+                return (dx if need[0] else None), gd, gn, gs, gb
+            # plain backward: one fused kernel with the reductions in float32 accumulators
+            want_gd = has_d and need[1]
+            want_gb = has_b and need[4]
+            want_gs = has_nz and has_s and need[3]
+            want_gn = has_nz and need[2]
+            dx = torch.empty_like(x)
+            acc = torch.zeros([n * c + c + 1], dtype=torch.float32, device=x.device)
+            gd_a, gb_a, gs_a = acc[:n * c], acc[n * c:n * c + c], acc[n * c + c:]
+            stride = ctx.noise_meta[2] if has_nz else 0
+            d32 = dcoefs.to(x.dtype).to(torch.float32).contiguous() if has_d else None
+            if x.numel():
+                with torch.cuda.device(x.device):
+                    native.check(native.lib().mg_bwd_fused(
+                        native.ptr(dy), native.ptr(None if ident else y), native.ptr(x if want_gd else None), native.ptr(d32),
+                        native.ptr(nz32 if want_gs else None), native.ptr(dx), native.ptr(gd_a if want_gd else None),
+                        native.ptr(gb_a if want_gb else None), native.ptr(gs_a if want_gs else None),
+                        native.dtype_code(x.dtype), idx, alpha, gain, clamp, stride, n, c, h * w, native.stream_ptr(x.device)))
+            gd = gd_a.reshape(n, c).to(dcoefs.dtype) if want_gd else None
+            gb = gb_a.to(ctx.b_dtype) if want_gb else None
+            gs = gs_a.reshape([]).to(ctx.s_dtype) if want_gs else None
+            gn = None
+            if want_gn:         # a caller-scaled noise tensor that wants its own gradient: not the hot path
+                dt, shp, stride = ctx.noise_meta
+                dpre = dx / dcoefs.to(dx.dtype).reshape(n, c, 1, 1) if has_d else dx
+                gn = ((dpre.sum(dim=1, keepdim=True) if stride else dpre.sum(dim=[0, 1])).reshape(shp) * nz_gain).to(dt)
+            return (dx if need[0] else None), gd, gn, gs, gb
 
     _cache[key] = ModconvEpilogue
     return ModconvEpilogue
 
 
-def modconv_epilogue(x, dcoefs=None, noise=None, b=None, act='lrelu', alpha=None, gain=None, clamp=None, impl='cuda'):
-    """y = clamp(act(x * dcoefs[N,C,1,1] + noise + b[C]) * gain).
+def modconv_epilogue(x, dcoefs=None, noise=None, b=None, act='lrelu', alpha=None, gain=None, clamp=None, impl='cuda',
+                     noise_strength=None):
+    """y = clamp(act(x * dcoefs[N,C,1,1] + noise * noise_strength + b[C]) * gain).
 
-    x [N,C,H,W]; dcoefs [N,C] or None; noise [H,W] / [1,1,H,W] (shared) or [N,1,H,W] (per sample),
-    already multiplied by its strength, or None; b [C] or None."""
+    x [N,C,H,W]; dcoefs [N,C] or None; noise [H,W] / [1,1,H,W] (shared) or [N,1,H,W] (per sample) or None;
+    noise_strength: 0-dim tensor multiplying `noise` (None: `noise` is already scaled); b [C] or None."""
     assert isinstance(x, torch.Tensor) and x.ndim == 4
     spec = _ba.activation_funcs[act]
     alpha = float(spec.def_alpha if alpha is None else alpha)
@@ -123,5 +155,54 @@ def modconv_epilogue(x, dcoefs=None, noise=None, b=None, act='lrelu', alpha=None
     clamp = float(-1 if clamp is None else clamp)
     fusable = 'x' not in spec.ref and not spec.has_2nd_grad
     if impl == 'cuda' and x.device.type == 'cuda' and x.dtype != torch.float64 and fusable and x.is_contiguous():
-        return _epilogue_hip(act, alpha, gain, clamp).apply(x, dcoefs, noise, b)
+        return _epilogue_hip(act, alpha, gain, clamp).apply(x, dcoefs, noise, noise_strength, b)
+    if noise is not None and noise_strength is not None:
+        noise = noise * noise_strength
     return _epilogue_ref(x, dcoefs, noise, b, act, alpha, gain, None if clamp < 0 else clamp)
+
+
+class _ChannelScale(torch.autograd.Function):
+    """y = x * s[N,C,1,1] on the native path; backward = one fused kernel (dx = dy*s, ds = sum_hw dy*x)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        n, c, h, w = x.shape
+        x = x.contiguous()
+        s32 = s.detach().to(x.dtype).to(torch.float32).contiguous()      # styles.to(x.dtype), as the reference
+        y = torch.empty_like(x)
+        if x.numel():
+            with torch.cuda.device(x.device):
+                native.check(native.lib().mg_fma_bias_act(native.ptr(x), native.ptr(s32), native.ptr(None), native.ptr(None),
+                                                          native.ptr(y), native.dtype_code(x.dtype), 1, 0.0, 1.0, -1.0, 1.0, native.ptr(None), 0,
+                                                          n, c, h * w, native.stream_ptr(x.device)))
+        ctx.save_for_backward(x, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s = ctx.saved_tensors
+        n, c, h, w = x.shape
+        if torch.is_grad_enabled():
+            dx = dy * s.to(dy.dtype).reshape(n, c, 1, 1) if ctx.needs_input_grad[0] else None
+            ds = (dy * x).sum(dim=[2, 3]).to(s.dtype) if ctx.needs_input_grad[1] else None
+            return dx, ds
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        want_ds = ctx.needs_input_grad[1]
+        gd = torch.zeros([n * c], dtype=torch.float32, device=x.device) if want_ds else None
+        s32 = s.to(x.dtype).to(torch.float32).contiguous()
+        if x.numel():
+            with torch.cuda.device(x.device):
+                native.check(native.lib().mg_bwd_fused(native.ptr(dy), native.ptr(None), native.ptr(x if want_ds else None),
+                                                       native.ptr(s32), native.ptr(None), native.ptr(dx), native.ptr(gd),
+                                                       native.ptr(None), native.ptr(None), native.dtype_code(x.dtype), 1, 0.0, 1.0,
+                                                       -1.0, 0, n, c, h * w, native.stream_ptr(x.device)))
+        return (dx if ctx.needs_input_grad[0] else None), (gd.reshape(n, c).to(s.dtype) if want_ds else None)
+
+
+def channel_scale(x, s, impl='cuda'):
+    """x [N,C,H,W] * s [N,C] broadcast over H,W -- the style modulation in front of a shared-weight convolution
+    (reference training/networks.py:70: ``x * styles.to(x.dtype).reshape(batch_size, -1, 1, 1)``)."""
+    if impl == 'cuda' and x.device.type == 'cuda' and x.dtype != torch.float64 and x.ndim == 4 and x.is_contiguous():
+        return _ChannelScale.apply(x, s)
+    return x * s.to(x.dtype).reshape(x.shape[0], -1, 1, 1)

@@ -236,34 +236,37 @@ class SynthesisLayer(torch.nn.Module):
         assert noise_mode in ['random', 'const', 'none']
         misc.assert_shape(x, [None, self.weight.shape[1], *_spatial(self.resolution // self.up, self.init_res, self.conv_config_index)])
         styles = self.affine(w)
-        noise = None
+        noise_raw = None            # unscaled noise; multiplied by noise_strength below (or inside the fused kernel)
         if self.use_noise and noise_mode == 'random':
-            noise = torch.randn([x.shape[0], 1, *_spatial(self.resolution, self.init_res, self.conv_config_index)],
-                                device=x.device) * self.noise_strength
+            noise_raw = torch.randn([x.shape[0], 1, *_spatial(self.resolution, self.init_res, self.conv_config_index)],
+                                    device=x.device)
         if self.use_noise and noise_mode == 'const':
-            noise = self.noise_const * self.noise_strength
+            noise_raw = self.noise_const
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         flip_weight = (self.up == 1)
 
         if fused_epilogue and not fused_modconv and x.device.type == 'cuda' and x.dtype != torch.float64:
-            # shared-weight convolution, then ONE pass: demodulate * x + noise + bias -> lrelu -> gain -> clamp
+            # native path: modulate (1 pass) -> shared-weight convolution -> ONE pass for
+            # demodulate * x + noise * strength + bias -> lrelu -> gain -> clamp
             n = int(x.shape[0])
             weight, st = self.weight, styles
             if x.dtype == torch.float16:
                 weight = weight * (1 / np.sqrt(np.prod(weight.shape[1:])) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
                 st = st / st.norm(float('inf'), dim=1, keepdim=True)
             dcoefs = _demod_coefs(weight, st)
-            y = x * st.to(x.dtype).reshape(n, -1, 1, 1)
+            y = modconv_epilogue.channel_scale(x, st)
             y = conv2d_resample.conv2d_resample(x=y, w=weight.to(x.dtype), f=self.resample_filter, up=self.up,
                                                 padding=self.padding, flip_weight=flip_weight)
             if y.is_contiguous():
-                return modconv_epilogue.modconv_epilogue(y, dcoefs, noise, self.bias, act=self.activation, gain=act_gain,
-                                                         clamp=act_clamp)
+                return modconv_epilogue.modconv_epilogue(y, dcoefs, noise_raw, self.bias, act=self.activation, gain=act_gain,
+                                                         clamp=act_clamp, noise_strength=self.noise_strength if noise_raw is not None else None)
+            noise = noise_raw * self.noise_strength if noise_raw is not None else None
             y = fma.fma(y, dcoefs.to(y.dtype).reshape(n, -1, 1, 1), noise.to(y.dtype)) if noise is not None else \
                 y * dcoefs.to(y.dtype).reshape(n, -1, 1, 1)
             return bias_act.bias_act(y, self.bias.to(y.dtype), act=self.activation, gain=act_gain, clamp=act_clamp)
 
+        noise = noise_raw * self.noise_strength if noise_raw is not None else None
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=flip_weight, fused_modconv=fused_modconv)
         return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=act_gain, clamp=act_clamp)

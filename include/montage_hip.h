@@ -62,6 +62,7 @@ enum {
     MG_K_TRANSLATE_BWD_INPUT = 7,
     MG_K_TRANSLATE_BWD_SHIFT = 8,
     MG_K_FILTERED_LRELU = 9,
+    MG_K_BWD_FUSED = 10,
     MG_K_COUNT = 16
 };
 
@@ -117,7 +118,9 @@ int mg_bias_act(const void* x, const void* b, const void* xref, const void* yref
 /* ---- fused modulated-conv epilogue ----------------------------------------
  * y = clamp(act(x * d[n,c] + noise[n,h,w] * noise_gain + b[c]) * gain), NCHW
  * contiguous; d (float32 [N,C]), noise (float32, sample n at noise + n*noise_stride_n:
- * stride 0 = one [H*W] map shared by the batch, H*W = per-sample maps) and b may each be NULL.
+ * stride 0 = one [H*W] map shared by the batch, H*W = per-sample maps) and b may each be NULL;
+ * the noise multiplier is noise_gain * (noise_gain_dev ? *noise_gain_dev : 1) -- a DEVICE scalar, so the
+ * learned noise_strength never has to be read back by the host.
  * One read and one write of x instead of the three round trips of
  * fma.fma + bias_act.bias_act (training/networks.py:86-88, 311-313).
  * mg_fma_bias_act_bwd: dx_pre = dy * act'(yref) * gain masked by the clamp
@@ -125,12 +128,26 @@ int mg_bias_act(const void* x, const void* b, const void* xref, const void* yref
  * `dpre` is non NULL, dx_pre itself (needed for d(d), d(noise), d(b) sums).    */
 int mg_fma_bias_act(const void* x, const float* d, const float* noise, const void* b,
                     void* y, int dtype, int act, float alpha, float gain, float clamp,
-                    float noise_gain, int64_t noise_stride_n,
+                    float noise_gain, const float* noise_gain_dev, int64_t noise_stride_n,
                     int32_t n, int32_t c, int32_t hw, void* stream);
 int mg_fma_bias_act_bwd(const void* dy, const void* yref, const float* d,
                         void* dx, void* dpre, int dtype, int act, float alpha,
                         float gain, float clamp, int32_t n, int32_t c, int32_t hw,
                         void* stream);
+
+/* ---- fused backward with reductions -----------------------------------------
+ * One pass for what autograd otherwise does in up to five: NCHW contiguous, planes (n,c) of hw elements.
+ *   dpre = yref ? dy * act'(yref) * gain masked by the clamp (bias_act order 1) : dy
+ *   dx   = d ? dpre * d[n,c] : dpre                      (written)
+ *   gd[n,c] += sum_hw dpre * x        (x, gd non NULL)   -- d(dcoefs) of the epilogue, d(styles) of the modulation
+ *   gb[c]   += sum_{n,hw} dpre        (gb non NULL)      -- d(bias)
+ *   gs[0]   += sum dpre * noise[n,hw] (noise, gs non NULL) -- d(noise_strength)
+ * gd/gb/gs are float32 accumulators the caller zero-fills (float atomics, one per workgroup and sum).
+ * Covers: bias_act backward + bias gradient (bias_act.py:186-196), the fma/bias_act epilogue backward
+ * (fma.py:31-47) and the backward of x * styles[N,C,1,1] (training/networks.py:70).                      */
+int mg_bwd_fused(const void* dy, const void* yref, const void* x, const float* d, const float* noise,
+                 void* dx, float* gd, float* gb, float* gs, int dtype, int act, float alpha, float gain,
+                 float clamp, int64_t noise_stride_n, int32_t n, int32_t c, int32_t hw, void* stream);
 
 /* ---- alpha composite -------------------------------------------------------
  * x: [B, L, 4, H, W] contiguous (RGB + alpha, values nominally in [0,1]);

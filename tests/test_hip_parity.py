@@ -491,3 +491,51 @@ def test_profiling_hooks_report_kernel_time(native):
     assert rec['bias_act']['launches'] == 5
     assert rec['bias_act']['ms'] > 0
     assert rec['bias_act']['bytes'] == 5 * 2 * x.numel() * 4
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+def test_fused_backward_reductions_match_unfused(native, dtype):
+    """mg_bwd_fused behind bias_act / channel_scale / modconv_epilogue: dx and the float32-accumulated
+    reductions (bias, dcoefs/styles, noise_strength gradients) against the unfused autograd graph."""
+    B, E = op('bias_act'), op('modconv_epilogue')
+    g = torch.Generator(device=DEV).manual_seed(9)
+    for shape in ([3, 6, 16, 16], [2, 5, 7, 9], [4, 8, 64, 64]):
+        n, c, h, w = shape
+        # (1) bias_act with bias gradient
+        x = torch.randn(shape, device=DEV, generator=g).to(dtype).requires_grad_(True)
+        b = torch.randn([c], device=DEV, generator=g).to(dtype).requires_grad_(True)
+        dy = torch.randn(shape, device=DEV, generator=g).to(dtype)
+        before = native.launch_count(native.K_BWD_FUSED)
+        y = B.bias_act(x, b, act='lrelu', clamp=1.5)
+        gx, gb = torch.autograd.grad([y], [x, b], [dy])
+        assert native.launch_count(native.K_BWD_FUSED) == before + 1
+        y2 = B.bias_act(x, b, act='lrelu', clamp=1.5, impl='ref')
+        rx, rb = torch.autograd.grad([y2], [x, b], [dy])
+        close_lowp(gx.float().cpu().numpy(), rx.float().cpu().numpy(), dtype, 'bias_act dx')
+        close_lowp(gb.float().cpu().numpy(), rb.float().cpu().numpy(), dtype, 'bias_act db')
+        # (2) channel scale
+        s = (torch.rand([n, c], device=DEV, generator=g) + 0.5).requires_grad_(True)
+        before = native.launch_count(native.K_BWD_FUSED)
+        ys = E.channel_scale(x, s)
+        gx, gs = torch.autograd.grad([ys], [x, s], [dy])
+        assert native.launch_count(native.K_BWD_FUSED) == before + 1
+        yr = x * s.to(dtype).reshape(n, c, 1, 1)
+        rx, rs = torch.autograd.grad([yr], [x, s], [dy])
+        close_lowp(ys.float().detach().cpu().numpy(), yr.float().detach().cpu().numpy(), dtype, 'scale fwd')
+        close_lowp(gx.float().cpu().numpy(), rx.float().cpu().numpy(), dtype, 'scale dx')
+        close_lowp(gs.float().cpu().numpy(), rs.float().cpu().numpy(), dtype, 'scale ds')
+        # (3) epilogue with raw noise + device-side strength, per-sample and shared noise
+        for per_sample in (False, True):
+            d = (torch.rand([n, c], device=DEV, generator=g) + 0.5).requires_grad_(True)
+            strength = torch.tensor(0.37, device=DEV, requires_grad=True)
+            raw = torch.randn([n, 1, h, w] if per_sample else [h, w], device=DEV, generator=g)
+            bb = torch.randn([c], device=DEV, generator=g).requires_grad_(True)
+            before = native.launch_count(native.K_BWD_FUSED)
+            y = E.modconv_epilogue(x, d, raw, bb, act='lrelu', clamp=256, noise_strength=strength)
+            grads = torch.autograd.grad([y], [x, d, strength, bb], [dy])
+            assert native.launch_count(native.K_BWD_FUSED) == before + 1
+            y2 = E.modconv_epilogue(x, d, raw * strength, bb, act='lrelu', clamp=256, impl='ref')
+            refs = torch.autograd.grad([y2], [x, d, strength, bb], [dy])
+            close_lowp(y.float().detach().cpu().numpy(), y2.float().detach().cpu().numpy(), dtype, 'epilogue fwd')
+            for u, v, nm in zip(grads, refs, ('x', 'dcoefs', 'strength', 'bias')):
+                close_lowp(u.float().cpu().numpy(), v.float().cpu().numpy(), dtype, f'epilogue grad {nm} per_sample={per_sample}')
