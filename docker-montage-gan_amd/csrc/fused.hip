@@ -29,7 +29,8 @@ template <class T, int A, int VEC>
 __global__ void __launch_bounds__(256) fma_bias_act_fwd_kernel(FbArgs<T> p)
 {
     struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
-    struct alignas(VEC >= 4 ? 16 : 4) NV { float v[VEC]; };
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    struct NV { float v[VEC]; };
     const BaConst<float> k = {p.alpha, p.gain, p.clamp};
     const uint32_t hwv = p.hw / VEC;
     const float ngain = p.noise_gain * ((p.noise && p.noise_gain_dev) ? *p.noise_gain_dev : 1.f);
@@ -47,8 +48,13 @@ __global__ void __launch_bounds__(256) fma_bias_act_fwd_kernel(FbArgs<T> p)
             if (p.noise) {
                 const uint32_t pv = vi - plane[u] * hwv, n = fd_div(plane[u], p.c_div);
                 const float* nz = p.noise + (int64_t)n * p.noise_stride_n + (size_t)pv * VEC;
-                if (nz_vec) nzv[u] = *(const NV*)nz;
-                else {
+                if (VEC >= 4 && nz_vec) {
+                    #pragma unroll
+                    for (int q = 0; q < VEC / 4; q++) {             // explicit 16-byte loads
+                        const f4_t t = ((const f4_t*)nz)[q];
+                        nzv[u].v[4 * q] = t.x; nzv[u].v[4 * q + 1] = t.y; nzv[u].v[4 * q + 2] = t.z; nzv[u].v[4 * q + 3] = t.w;
+                    }
+                } else {
                     #pragma unroll
                     for (int e = 0; e < VEC; e++) nzv[u].v[e] = nz[e];
                 }
