@@ -42,6 +42,11 @@ def build_trainer(args, device, rank, world):
         TL = mod('custom.training_loop_aio')
         DS = mod('custom.dataset_aio')
         kw = TL.default_kwargs(num_gpus=world, batch_gpu=args.batch_gpu, num_fp16_res=nfp16, fp16_dtype=dtype)
+        if not args.no_ada:
+            AU = mod('training.augment')
+            AU.fixed_margin = True          # no device->host read-back per D call (training/augment.py docstring)
+            kw.augment_kwargs = dict(class_name='training.augment.AugmentPipe', **AU.augpipe_specs['bgc'])
+            kw.augment_p, kw.ada_target = args.ada_p, None          # fixed p: timing determinism
         kw.training_set_kwargs.num_layers = args.layers
         kw.training_set_kwargs.resolution = args.res
         if args.tiny:
@@ -55,10 +60,15 @@ def build_trainer(args, device, rank, world):
         reals = [DS.synthetic_layers(args.batch_gpu, args.layers, args.res, seed=1000 * rank + i, device=device) for i in range(2)]
         trainer = TL.AioTrainer(rank=rank, device=device, cfg=cfg, resident_batches=reals, random_seed=0, **kw)
         name = (f'train_aio full step: {args.layers} local StyleGAN2 (G+D) + global GAN (STN + alpha composite + D), '
-                f'{args.res}x{args.res} RGBA, bypass_renderer, no ADA')
+                f'{args.res}x{args.res} RGBA, bypass_renderer, ' + ('no ADA' if args.no_ada else f'ADA bgc at fixed p={args.ada_p}'))
     else:
         TL = mod('training.training_loop')
         kw = TL.default_kwargs(num_gpus=world, batch_gpu=args.batch_gpu, resolution=args.res, num_fp16_res=nfp16, fp16_dtype=dtype)
+        if not args.no_ada:
+            AU = mod('training.augment')
+            AU.fixed_margin = True
+            kw.augment_kwargs = dict(class_name='training.augment.AugmentPipe', **AU.augpipe_specs['bgc'])
+            kw.augment_p, kw.ada_target = args.ada_p, None
         if args.tiny:
             kw.G_kwargs.synthesis_kwargs.channel_base = kw.D_kwargs.channel_base = 512
             kw.G_kwargs.synthesis_kwargs.channel_max = kw.D_kwargs.channel_max = 32
@@ -66,7 +76,7 @@ def build_trainer(args, device, rank, world):
         reals = [(torch.randint(0, 256, [args.batch_gpu, 4, args.res, args.res], generator=g, dtype=torch.uint8).to(device),
                   torch.zeros([args.batch_gpu, 0], device=device)) for _ in range(2)]
         trainer = TL.Trainer(rank=rank, device=device, resident_batches=reals, random_seed=0, **kw)
-        name = f'train.py step: one StyleGAN2 G+D, {args.res}x{args.res} RGBA, no ADA'
+        name = f'train.py step: one StyleGAN2 G+D, {args.res}x{args.res} RGBA, ' + ('no ADA' if args.no_ada else f'ADA bgc at fixed p={args.ada_p}')
     return trainer, name
 
 
@@ -134,6 +144,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--prof-steps', type=int, default=4, help='extra (untimed) steps with per-kernel HIP events for the roofline object')
     ap.add_argument('--no-stats', action='store_true', help='turn training_stats.report into a no-op')
+    ap.add_argument('--no-ada', action='store_true', help='run without the ADA augmentation pipe (default: bgc at fixed p = 0.3, SURVEY 8d)')
+    ap.add_argument('--ada-p', type=float, default=0.3)
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark=True (MIOpen exhaustive find; minutes of warm-up on a fresh box)')
     ap.add_argument('--quiet', action='store_true')
     ap.add_argument('--channels-last', action='store_true', help='experiment: NHWC activations in the reduced-precision blocks')

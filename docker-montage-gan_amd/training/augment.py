@@ -8,8 +8,12 @@ RGBA branch of the colour stage :403-406), so that a seeded CPU run reproduces i
 It is the main consumer of the separable resampler: the geometric stage is
 ``pad(reflect) -> upfirdn2d.upsample2d(sym6, x2) -> grid_sample_gradfix.grid_sample -> upfirdn2d.downsample2d(sym6, /2)``
 i.e. four launches of csrc/upfirdn2d.hip (two separable passes each) around aten's sampler.
-Host-sync note: the reflect-padding margin is data dependent and read back as python ints (one sync per
-call, as upstream :313); removing it means a fused pad+sample kernel -- SURVEY 8(f) rank 1, not done yet.
+Host-sync note: upstream reads the data-dependent reflect-padding margin back as python ints (:313), one
+device->host synchronisation per discriminator call -- on a GPU-bound step that serialises host and device time.
+``fixed_margin = True`` (module switch, off by default = upstream behaviour) pads by the clamp bound
+(width-1, height-1) instead: the margin is only an upper bound of what the sampler may touch, so the result is
+the same up to float rounding of the grid coordinates, the 4-channel images get 9x larger for two FIR passes
+(about 1 ms at 32x4x256x256), and the step never waits for the host.
 """
 import numpy as np
 import scipy.signal
@@ -19,6 +23,8 @@ from ..torch_utils import misc
 from ..torch_utils.ops import conv2d_gradfix
 from ..torch_utils.ops import grid_sample_gradfix
 from ..torch_utils.ops import upfirdn2d
+
+fixed_margin = False      # True: never read the padding margin back to the host (see module docstring)
 
 # Orthogonal wavelet low-pass filters (Daubechies / symlets), as tabulated in PyWavelets.
 wavelets = {
@@ -196,7 +202,10 @@ class AugmentPipe(torch.nn.Module):
             margin = torch.cat([-margin, margin]).max(dim=1).values             # [x0, y0, x1, y1]
             margin = margin + misc.constant([hz_pad * 2 - cx, hz_pad * 2 - cy] * 2, device=dev)
             margin = margin.max(misc.constant([0, 0] * 2, device=dev)).min(misc.constant([width - 1, height - 1] * 2, device=dev))
-            mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().to(torch.int32).tolist())       # the one host sync
+            if fixed_margin:
+                mx0, my0, mx1, my1 = width - 1, height - 1, width - 1, height - 1                  # the clamp bound: no read-back
+            else:
+                mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().to(torch.int32).tolist())   # the one host sync
             images = torch.nn.functional.pad(input=images, pad=[mx0, mx1, my0, my1], mode='reflect')
             G_inv = translate2d((mx0 - mx1) / 2, (my0 - my1) / 2, device=dev) @ G_inv
             # x2 upsample with the 12-tap symlet (separable -> two native passes)

@@ -74,3 +74,23 @@ def test_layout_glue_matches_reference():
     assert crop.shape == (4, 29, 59)            # the max row/column is excluded, as upstream
     np.testing.assert_allclose(IU.pad_256(crop).numpy(), pf[0, 0].numpy(), atol=0)
     assert IU.crop_to_content(lay[1, 1]).shape == (4, 0, 0)        # empty layer
+
+
+def test_fixed_margin_mode_gives_the_same_images():
+    """augment.fixed_margin pads by the clamp bound instead of reading the margin back: same output."""
+    AU = mod('training.augment')
+    cases, arr = load_golden('augment')
+    n = 0
+    for c in cases:
+        if c['op'] != 'augment' or c['spec'] != 'bgc':
+            continue
+        AU.fixed_margin = True
+        try:
+            y, dx = run_augment_case(c, arr)
+        finally:
+            AU.fixed_margin = False
+        np.testing.assert_allclose(y.detach().numpy(), arr[f'c{c["id"]}_y'], rtol=1e-4, atol=5e-5, err_msg=str(c))
+        if dx is not None:
+            np.testing.assert_allclose(dx.numpy(), arr[f'c{c["id"]}_dx'], rtol=1e-4, atol=5e-5, err_msg=str(c))
+        n += 1
+    assert n == 10

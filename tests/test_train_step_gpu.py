@@ -132,3 +132,30 @@ def test_aio_iteration_runs_native_and_updates_weights():
     assert any(not torch.equal(a, b) for a, b in zip(w0, w1))
     assert all(torch.isfinite(p).all() for g in t.local_G_list for p in g.parameters())
     assert not torch.equal(stn0, t.pos_estimator.fc_loc[2].bias.detach())       # the STN learns a placement
+
+
+def test_augment_pipe_on_gpu_matches_reference_golden():
+    """Deterministic (debug_percentile) AugmentPipe images on the GPU -- native separable upfirdn2d passes around
+    aten's grid sampler -- against the reference's CPU output; also in the sync-free fixed-margin mode."""
+    from test_augment_layout_golden import run_augment_case
+    AU = mod('training.augment')
+    native = load_pkg().native
+    cases, arr = load_golden('augment')
+    GS = mod('torch_utils.ops.grid_sample_gradfix')
+    GS.enabled = True
+    try:
+        for fixed in (False, True):
+            AU.fixed_margin = fixed
+            before = native.launch_counts()
+            n = 0
+            for c in cases:
+                if c['op'] != 'augment' or c['debug_percentile'] is None:
+                    continue
+                y, _ = run_augment_case(c, arr, device=DEV)
+                np.testing.assert_allclose(y.cpu().numpy(), arr[f'c{c["id"]}_y'], rtol=1e-3, atol=1e-3, err_msg=f'{c} fixed={fixed}')
+                n += 1
+            after = native.launch_counts()
+            assert n == 9 and after['upfirdn2d_tiled'] + after['upfirdn2d_generic'] >= before['upfirdn2d_tiled'] + before['upfirdn2d_generic'] + 4 * n
+    finally:
+        AU.fixed_margin = False
+        GS.enabled = False
