@@ -149,13 +149,14 @@ def test_augment_pipe_on_gpu_matches_reference_golden():
             before = native.launch_counts()
             n = 0
             for c in cases:
-                if c['op'] != 'augment' or c['debug_percentile'] is None:
+                # 'all' adds image noise, which is random even under debug_percentile: device RNG differs from the CPU's
+                if c['op'] != 'augment' or c['debug_percentile'] is None or c['spec'] != 'bgc':
                     continue
                 y, _ = run_augment_case(c, arr, device=DEV)
                 np.testing.assert_allclose(y.cpu().numpy(), arr[f'c{c["id"]}_y'], rtol=1e-3, atol=1e-3, err_msg=f'{c} fixed={fixed}')
                 n += 1
             after = native.launch_counts()
-            assert n == 9 and after['upfirdn2d_tiled'] + after['upfirdn2d_generic'] >= before['upfirdn2d_tiled'] + before['upfirdn2d_generic'] + 4 * n
+            assert n == 6 and after['upfirdn2d_tiled'] + after['upfirdn2d_generic'] >= before['upfirdn2d_tiled'] + before['upfirdn2d_generic'] + 4 * n
     finally:
         AU.fixed_margin = False
         GS.enabled = False
