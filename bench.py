@@ -44,7 +44,8 @@ def build_trainer(args, device, rank, world):
         kw = TL.default_kwargs(num_gpus=world, batch_gpu=args.batch_gpu, num_fp16_res=nfp16, fp16_dtype=dtype)
         if not args.no_ada:
             AU = mod('training.augment')
-            AU.fixed_margin = True          # no device->host read-back per D call (training/augment.py docstring)
+            # do not wait for the whole queued step at every D call (training/augment.py docstring)
+            AU.side_stream_margin, AU.fixed_margin = args.ada_margin == 'side', args.ada_margin == 'fixed'
             kw.augment_kwargs = dict(class_name='training.augment.AugmentPipe', **AU.augpipe_specs['bgc'])
             kw.augment_p, kw.ada_target = args.ada_p, None          # fixed p: timing determinism
         kw.training_set_kwargs.num_layers = args.layers
@@ -66,7 +67,7 @@ def build_trainer(args, device, rank, world):
         kw = TL.default_kwargs(num_gpus=world, batch_gpu=args.batch_gpu, resolution=args.res, num_fp16_res=nfp16, fp16_dtype=dtype)
         if not args.no_ada:
             AU = mod('training.augment')
-            AU.fixed_margin = True
+            AU.side_stream_margin, AU.fixed_margin = args.ada_margin == 'side', args.ada_margin == 'fixed'
             kw.augment_kwargs = dict(class_name='training.augment.AugmentPipe', **AU.augpipe_specs['bgc'])
             kw.augment_p, kw.ada_target = args.ada_p, None
         if args.tiny:
@@ -146,6 +147,8 @@ def main():
     ap.add_argument('--no-stats', action='store_true', help='turn training_stats.report into a no-op')
     ap.add_argument('--no-ada', action='store_true', help='run without the ADA augmentation pipe (default: bgc at fixed p = 0.3, SURVEY 8d)')
     ap.add_argument('--ada-p', type=float, default=0.3)
+    ap.add_argument('--ada-margin', default='side', choices=['side', 'fixed', 'sync'],
+                    help='how AugmentPipe learns its padding margin: side-stream read-back (default), clamp bound, or blocking read-back as upstream')
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark=True (MIOpen exhaustive find; minutes of warm-up on a fresh box)')
     ap.add_argument('--quiet', action='store_true')
     ap.add_argument('--channels-last', action='store_true', help='experiment: NHWC activations in the reduced-precision blocks')

@@ -10,10 +10,13 @@ It is the main consumer of the separable resampler: the geometric stage is
 i.e. four launches of csrc/upfirdn2d.hip (two separable passes each) around aten's sampler.
 Host-sync note: upstream reads the data-dependent reflect-padding margin back as python ints (:313), one
 device->host synchronisation per discriminator call -- on a GPU-bound step that serialises host and device time.
-``fixed_margin = True`` (module switch, off by default = upstream behaviour) pads by the clamp bound
-(width-1, height-1) instead: the margin is only an upper bound of what the sampler may touch, so the result is
-the same up to float rounding of the grid coordinates, the 4-channel images get 9x larger for two FIR passes
-(about 1 ms at 32x4x256x256), and the step never waits for the host.
+Two module switches remove that wait (both off by default = upstream behaviour):
+  * ``side_stream_margin = True``: the transform parameters and the margin are computed on a separate HIP stream
+    that does not queue behind the training step; the host waits only for those few tiny kernels, reads the four
+    ints from pinned memory, and the main stream picks the matrices up through an event.  Same random draws, same
+    margins, same images -- only the wait shrinks from "the whole backlog" to microseconds.
+  * ``fixed_margin = True``: pad by the clamp bound (width-1, height-1) with no read-back at all; same images up to
+    float rounding of the grid coordinates, but the 4-channel tensors of the geometric stage get 9x larger.
 """
 import numpy as np
 import scipy.signal
@@ -24,7 +27,9 @@ from ..torch_utils.ops import conv2d_gradfix
 from ..torch_utils.ops import grid_sample_gradfix
 from ..torch_utils.ops import upfirdn2d
 
-fixed_margin = False      # True: never read the padding margin back to the host (see module docstring)
+fixed_margin = False          # True: never read the padding margin back to the host (see module docstring)
+side_stream_margin = False    # True: compute transform parameters + margin on a side stream, wait only for that
+_side_streams = dict()
 
 # Orthogonal wavelet low-pass filters (Daubechies / symlets), as tabulated in PyWavelets.
 wavelets = {
@@ -132,13 +137,9 @@ class AugmentPipe(torch.nn.Module):
     def _gate(value, prob, neutral, shape, device):
         return torch.where(torch.rand(shape, device=device) < prob, value, neutral)
 
-    def forward(self, images, debug_percentile=None):
-        assert isinstance(images, torch.Tensor) and images.ndim == 4
-        n, ch, height, width = images.shape
-        dev = images.device
-        dp = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32, device=dev)
+    def _geometric_params(self, n, height, width, dev, dp):
+        """Random draws of the blit/geometric stage -> (G_inv [n,3,3] or the identity object, I_3, margin [4] or None)."""
         rand, randn = (lambda *s: torch.rand(list(s), device=dev)), (lambda *s: torch.randn(list(s), device=dev))
-
         # ---- pixel blitting + general geometric transforms, accumulated as one inverse matrix ----
         I_3 = torch.eye(3, device=dev)
         G_inv = I_3
@@ -192,6 +193,7 @@ class AugmentPipe(torch.nn.Module):
                 t = torch.full_like(t, torch.erfinv(dp * 2 - 1) * self.xfrac_std)
             G_inv = G_inv @ translate2d_inv(t[:, 0] * width, t[:, 1] * height)
 
+        margin = None
         if G_inv is not I_3:
             # how far do the transformed image corners reach?  -> reflect padding needed
             cx, cy = (width - 1) / 2, (height - 1) / 2
@@ -202,8 +204,43 @@ class AugmentPipe(torch.nn.Module):
             margin = torch.cat([-margin, margin]).max(dim=1).values             # [x0, y0, x1, y1]
             margin = margin + misc.constant([hz_pad * 2 - cx, hz_pad * 2 - cy] * 2, device=dev)
             margin = margin.max(misc.constant([0, 0] * 2, device=dev)).min(misc.constant([width - 1, height - 1] * 2, device=dev))
+        return G_inv, I_3, margin
+
+    def forward(self, images, debug_percentile=None):
+        assert isinstance(images, torch.Tensor) and images.ndim == 4
+        n, ch, height, width = images.shape
+        dev = images.device
+        dp = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32, device=dev)
+        rand, randn = (lambda *s: torch.rand(list(s), device=dev)), (lambda *s: torch.randn(list(s), device=dev))
+
+        # ---- pixel blitting + general geometric transforms (one inverse matrix) and the padding they need ----
+        use_side = side_stream_margin and images.is_cuda and not fixed_margin
+        if use_side:
+            main = torch.cuda.current_stream(dev)
+            side = _side_streams.get(dev)
+            if side is None:
+                side = _side_streams[dev] = torch.cuda.Stream(device=dev, priority=-1)
+            if not hasattr(self, '_pinned_margin'):
+                self._pinned_margin = torch.empty([4], dtype=torch.int32).pin_memory()
+            with torch.cuda.stream(side):
+                G_inv, I_3, margin = self._geometric_params(n, height, width, dev, dp)
+                if margin is not None:
+                    self._pinned_margin.copy_(margin.ceil().to(torch.int32), non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(side)
+            done.synchronize()                  # the host waits for the side stream only
+            main.wait_event(done)
+            if G_inv is not I_3:
+                G_inv.record_stream(main)
+        else:
+            G_inv, I_3, margin = self._geometric_params(n, height, width, dev, dp)
+        if G_inv is not I_3:
+            cx, cy = (width - 1) / 2, (height - 1) / 2
+            hz_pad = self.Hz_geom.shape[0] // 4
             if fixed_margin:
                 mx0, my0, mx1, my1 = width - 1, height - 1, width - 1, height - 1                  # the clamp bound: no read-back
+            elif use_side:
+                mx0, my0, mx1, my1 = (int(v) for v in self._pinned_margin.tolist())             # already on the host
             else:
                 mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().to(torch.int32).tolist())   # the one host sync
             images = torch.nn.functional.pad(input=images, pad=[mx0, mx1, my0, my1], mode='reflect')

@@ -144,8 +144,8 @@ def test_augment_pipe_on_gpu_matches_reference_golden():
     GS = mod('torch_utils.ops.grid_sample_gradfix')
     GS.enabled = True
     try:
-        for fixed in (False, True):
-            AU.fixed_margin = fixed
+        for fixed, side in ((False, False), (True, False), (False, True)):
+            AU.fixed_margin, AU.side_stream_margin = fixed, side
             before = native.launch_counts()
             n = 0
             for c in cases:
@@ -158,5 +158,5 @@ def test_augment_pipe_on_gpu_matches_reference_golden():
             after = native.launch_counts()
             assert n == 6 and after['upfirdn2d_tiled'] + after['upfirdn2d_generic'] >= before['upfirdn2d_tiled'] + before['upfirdn2d_generic'] + 4 * n
     finally:
-        AU.fixed_margin = False
+        AU.fixed_margin = AU.side_stream_margin = False
         GS.enabled = False
