@@ -261,22 +261,35 @@ __global__ void __launch_bounds__(256) bwd_fused_kernel(BrArgs<T> p)
     const float dc = p.d ? p.d[plane] : 1.f;
     const float* nz = p.noise ? p.noise + (int64_t)n * p.noise_stride_n : nullptr;
     float s_gd = 0.f, s_gb = 0.f, s_gs = 0.f;
-    for (uint32_t i = lo + threadIdx.x * VEC; i < hi; i += 256u * VEC) {
+    constexpr int BU = 4;                                           // vectors in flight per lane
+    for (uint32_t i0 = lo + threadIdx.x * VEC; i0 < hi; i0 += 256u * VEC * BU) {
         // hw % VEC == 0 on the vector path, so a vector never crosses the end of the plane
-        V vdy = *(const V*)(p.dy + base + i), vy, vx, out;
-        if (p.yref) vy = *(const V*)(p.yref + base + i);
-        if (p.x) vx = *(const V*)(p.x + base + i);
+        V vdy[BU], vy[BU], vx[BU];
         #pragma unroll
-        for (int e = 0; e < VEC; e++) {
-            float g = to_acc<T>(vdy.v[e]);
-            if (p.yref) g = ba_eval<float, A>(1, g, 0.f, 0.f, to_acc<T>(vy.v[e]), 1.f, k);
-            const float gq = to_acc<T>(from_acc<T>(g));            // autograd materialises dpre in T
-            out.v[e] = from_acc<T>(gq * dc);
-            s_gb += gq;
-            if (p.x) s_gd += gq * to_acc<T>(vx.v[e]);
-            if (nz) s_gs += gq * nz[i + e];
+        for (int u = 0; u < BU; u++) {
+            const uint32_t i = i0 + u * 256u * VEC;
+            if (i >= hi) continue;
+            vdy[u] = *(const V*)(p.dy + base + i);
+            if (p.yref) vy[u] = *(const V*)(p.yref + base + i);
+            if (p.x) vx[u] = *(const V*)(p.x + base + i);
         }
-        *(V*)(p.dx + base + i) = out;
+        #pragma unroll
+        for (int u = 0; u < BU; u++) {
+            const uint32_t i = i0 + u * 256u * VEC;
+            if (i >= hi) continue;
+            V out;
+            #pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                float g = to_acc<T>(vdy[u].v[e]);
+                if (p.yref) g = ba_eval<float, A>(1, g, 0.f, 0.f, to_acc<T>(vy[u].v[e]), 1.f, k);
+                const float gq = to_acc<T>(from_acc<T>(g));        // autograd materialises dpre in T
+                out.v[e] = from_acc<T>(gq * dc);
+                s_gb += gq;
+                if (p.x) s_gd += gq * to_acc<T>(vx[u].v[e]);
+                if (nz) s_gs += gq * nz[i + e];
+            }
+            *(V*)(p.dx + base + i) = out;
+        }
     }
     #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -299,7 +312,7 @@ void launch_br(BrArgs<T> p, bool wide, uint32_t planes, hipStream_t s)
     constexpr int VEC = 16 / sizeof(T);
     const uint32_t vec = wide ? VEC : 1;
     const uint32_t unit = 256u * vec;
-    uint32_t slices = (p.hw + unit * 8 - 1) / (unit * 8);          // about 8 vectors per lane per slice
+    uint32_t slices = (p.hw + unit * 8 - 1) / (unit * 8);          // about 8 vectors per lane per slice (2 rounds of 4 in flight)
     if (slices < 1) slices = 1;
     if (slices > 64) slices = 64;
     uint32_t len = (p.hw + slices - 1) / slices;
