@@ -260,11 +260,14 @@ __global__ void __launch_bounds__(256) bwd_fused_kernel(BrArgs<T> p)
     const uint32_t lo = slice * p.slice_len, hi = min(p.hw, lo + p.slice_len);
     const float dc = p.d ? p.d[plane] : 1.f;
     const float* nz = p.noise ? p.noise + (int64_t)n * p.noise_stride_n : nullptr;
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    const bool nz_vec = (VEC == 1) || ((((uintptr_t)p.noise) & 15) == 0 && ((p.noise_stride_n * 4) & 15) == 0);
     float s_gd = 0.f, s_gb = 0.f, s_gs = 0.f;
     constexpr int BU = 4;                                           // vectors in flight per lane
     for (uint32_t i0 = lo + threadIdx.x * VEC; i0 < hi; i0 += 256u * VEC * BU) {
         // hw % VEC == 0 on the vector path, so a vector never crosses the end of the plane
         V vdy[BU], vy[BU], vx[BU];
+        float nzv[BU][VEC];
         #pragma unroll
         for (int u = 0; u < BU; u++) {
             const uint32_t i = i0 + u * 256u * VEC;
@@ -272,6 +275,18 @@ __global__ void __launch_bounds__(256) bwd_fused_kernel(BrArgs<T> p)
             vdy[u] = *(const V*)(p.dy + base + i);
             if (p.yref) vy[u] = *(const V*)(p.yref + base + i);
             if (p.x) vx[u] = *(const V*)(p.x + base + i);
+            if (nz) {
+                if (VEC >= 4 && nz_vec) {
+                    #pragma unroll
+                    for (int q = 0; q < VEC / 4; q++) {
+                        const f4_t t = ((const f4_t*)(nz + i))[q];
+                        nzv[u][4 * q] = t.x; nzv[u][4 * q + 1] = t.y; nzv[u][4 * q + 2] = t.z; nzv[u][4 * q + 3] = t.w;
+                    }
+                } else {
+                    #pragma unroll
+                    for (int e = 0; e < VEC; e++) nzv[u][e] = nz[i + e];
+                }
+            }
         }
         #pragma unroll
         for (int u = 0; u < BU; u++) {
@@ -286,7 +301,7 @@ __global__ void __launch_bounds__(256) bwd_fused_kernel(BrArgs<T> p)
                 out.v[e] = from_acc<T>(gq * dc);
                 s_gb += gq;
                 if (p.x) s_gd += gq * to_acc<T>(vx[u].v[e]);
-                if (nz) s_gs += gq * nz[i + e];
+                if (nz) s_gs += gq * nzv[u][e];
             }
             *(V*)(p.dx + base + i) = out;
         }
