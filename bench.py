@@ -152,6 +152,8 @@ def main():
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark=True (MIOpen exhaustive find; minutes of warm-up on a fresh box)')
     ap.add_argument('--quiet', action='store_true')
     ap.add_argument('--channels-last', action='store_true', help='experiment: NHWC activations in the reduced-precision blocks')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow)')
+    ap.add_argument('--share-gpu', action='store_true', help='rehearsal only: every rank uses cuda:0')
     ap.add_argument('--marker-file', default=None, help='write clock readings at the start/end of the timed region (for cutting a rocprofv3 trace)')
     args = ap.parse_args()
     if args.batch_gpu is None:
@@ -162,11 +164,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1'
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.distributed.init_process_group(backend='nccl', device_id=device)        # nccl == RCCL on ROCm
+        if args.backend == 'nccl':
+            torch.distributed.init_process_group(backend='nccl', device_id=device)    # nccl == RCCL on ROCm
+        else:
+            torch.distributed.init_process_group(backend=args.backend)
 
     native = mod('torch_utils.native')
     native.lib()                                # fail loudly if the HIP library is missing
@@ -185,9 +192,10 @@ def main():
     progress(f'built {workload}; batch/gpu {args.batch_gpu}; phases {len(trainer.phases)}')
 
     def sync_all():
+        torch.cuda.synchronize(device)
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize(device)
+            torch.cuda.synchronize(device)
 
     for i in range(args.warmup):
         t_w = time.perf_counter()
@@ -218,15 +226,19 @@ def main():
 
     # per-kernel timing of the hand-written kernels (extra steps, outside the timed region)
     roofline = None
-    if rank == 0 and args.prof_steps > 0:
-        native.prof_reset()
-        native.prof_enable(True)
+    if args.prof_steps > 0:
+        # every rank runs these steps (they contain the gradient all-reduces); only rank 0 records events
+        if rank == 0:
+            native.prof_reset()
+            native.prof_enable(True)
         for _ in range(args.prof_steps):
             trainer.run_iteration()
         torch.cuda.synchronize(device)
-        rec = native.prof_collect()
-        native.prof_enable(False)
-        native.prof_reset()
+        rec = None
+        if rank == 0:
+            rec = native.prof_collect()
+            native.prof_enable(False)
+            native.prof_reset()
         if rec:
             total_ms = sum(v['ms'] for v in rec.values())
             name, top = max(rec.items(), key=lambda kv: kv[1]['ms'])
@@ -249,9 +261,6 @@ def main():
                             all_kernels={k: dict(ms_per_step=round(v['ms'] / args.prof_steps, 3), launches_per_step=round(v['launches'] / args.prof_steps, 1),
                                                  GBps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1)) for k, v in rec.items()},
                             native_ms_per_step=round(total_ms / args.prof_steps, 3))
-    elif world > 1:
-        for _ in range(0):
-            pass
 
     if rank == 0:
         imgs = args.batch_gpu * world * args.steps
