@@ -61,6 +61,7 @@ MgLaunchScope::~MgLaunchScope()
     if (!rec) return;
     ProfRec* r = (ProfRec*)rec;
     (void)hipEventRecord(r->b, stream);
+    r->kid = kid;                        // the launcher may have re-labelled the scope (e.g. tiled -> stream)
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_recs.push_back(*r);
     delete r;

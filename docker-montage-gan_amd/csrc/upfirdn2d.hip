@@ -426,7 +426,9 @@ bool try_stream(const UfParams& p, hipStream_t s)
     return true;
 }
 
-// Returns true when a tiled specialisation took the call.
+static thread_local bool g_last_was_stream = false;
+
+// Returns true when a tiled (or the streaming) specialisation took the call.
 template <class T>
 bool try_tiled(const UfParams& p, hipStream_t s)
 {
@@ -434,7 +436,7 @@ bool try_tiled(const UfParams& p, hipStream_t s)
                        p.xs_n == (int64_t)p.c * p.in_h * p.in_w && p.ys_w == 1 && p.ys_h == p.out_w &&
                        p.ys_c == (int64_t)p.out_h * p.out_w && p.ys_n == (int64_t)p.c * p.out_h * p.out_w;
     if (!dense) return false;
-    if (sizeof(T) <= 4 && try_stream<T>(p, s)) return true;
+    if (sizeof(T) <= 4 && try_stream<T>(p, s)) { g_last_was_stream = true; return true; }
     const int ux = p.upx, uy = p.upy, dx = p.downx, dy = p.downy, fw = p.f_w, fh = p.f_h;
 #define UF_CASE(UX, UY, DX, DY, FW_, FH_, MX_, MY_)                                                       \
     if (ux == UX && uy == UY && dx == DX && dy == DY && fw <= FW_ && fh <= FH_) {                         \
@@ -491,6 +493,7 @@ extern "C" int mg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
     bool tiled = false;
     {
         MgLaunchScope scope(MG_K_UPFIRDN2D_TILED, s, (double)(xn + yn) * es);
+        g_last_was_stream = false;
         switch (dtype) {
         case MG_F32:  tiled = try_tiled<float>(p, s); break;
         case MG_F16:  tiled = try_tiled<mg_half>(p, s); break;
@@ -498,8 +501,9 @@ extern "C" int mg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
         default: break;
         }
         if (!tiled) scope.kid = -1;
+        else if (g_last_was_stream) scope.kid = MG_K_UPFIRDN2D_STREAM;
     }
-    if (tiled) return mg_check_launch(MG_K_UPFIRDN2D_TILED, "upfirdn2d");
+    if (tiled) return mg_check_launch(g_last_was_stream ? MG_K_UPFIRDN2D_STREAM : MG_K_UPFIRDN2D_TILED, "upfirdn2d");
 
     MgLaunchScope scope(MG_K_UPFIRDN2D_GENERIC, s, (double)(xn + yn) * es);
     uint32_t total = (uint32_t)yn;

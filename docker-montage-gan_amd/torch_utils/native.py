@@ -17,10 +17,10 @@ LIB_PATH = os.environ.get('MONTAGE_HIP_LIB', os.path.join(CSRC, 'libmontage_hip.
 MG_F32, MG_F16, MG_BF16, MG_F64 = 0, 1, 2, 3
 K_UPFIRDN2D_GENERIC, K_UPFIRDN2D_TILED, K_BIAS_ACT, K_FMA_BIAS_ACT = 0, 1, 2, 3
 K_ALPHA_COMPOSITE_FWD, K_ALPHA_COMPOSITE_BWD, K_TRANSLATE_FWD, K_TRANSLATE_BWD_INPUT = 4, 5, 6, 7
-K_TRANSLATE_BWD_SHIFT, K_FILTERED_LRELU, K_BWD_FUSED = 8, 9, 10
+K_TRANSLATE_BWD_SHIFT, K_FILTERED_LRELU, K_BWD_FUSED, K_UPFIRDN2D_STREAM = 8, 9, 10, 11
 KERNEL_NAMES = {0: 'upfirdn2d_generic', 1: 'upfirdn2d_tiled', 2: 'bias_act', 3: 'fma_bias_act', 4: 'alpha_composite_fwd',
                 5: 'alpha_composite_bwd', 6: 'translate_fwd', 7: 'translate_bwd_input', 8: 'translate_bwd_shift',
-                9: 'filtered_lrelu', 10: 'bwd_fused'}
+                9: 'filtered_lrelu', 10: 'bwd_fused', 11: 'upfirdn2d_stream'}
 
 _lib = None
 _lock = threading.Lock()

@@ -63,6 +63,7 @@ enum {
     MG_K_TRANSLATE_BWD_SHIFT = 8,
     MG_K_FILTERED_LRELU = 9,
     MG_K_BWD_FUSED = 10,
+    MG_K_UPFIRDN2D_STREAM = 11,
     MG_K_COUNT = 16
 };
 

@@ -49,7 +49,7 @@ def close_lowp(got, want, dtype, what=''):
 def test_upfirdn2d_golden_fwd_bwd(native):
     U = op('upfirdn2d')
     cases, arr = load_golden('upfirdn2d')
-    before = native.launch_count(native.K_UPFIRDN2D_GENERIC) + native.launch_count(native.K_UPFIRDN2D_TILED)
+    before = native.launch_count(native.K_UPFIRDN2D_GENERIC) + native.launch_count(native.K_UPFIRDN2D_TILED) + native.launch_count(native.K_UPFIRDN2D_STREAM)
     for c in cases:
         i = c['id']
         y, dx = run_upfirdn2d_case(U, c, arr, device=DEV, impl='cuda')
@@ -58,7 +58,7 @@ def test_upfirdn2d_golden_fwd_bwd(native):
             assert y.is_contiguous(memory_format=torch.channels_last), c      # suggest_memory_format (upfirdn2d.cpp:35)
         np.testing.assert_allclose(y.detach().cpu().numpy(), arr[f'c{i}_y'], rtol=1e-4, atol=1e-5, err_msg=str(c))
         np.testing.assert_allclose(dx.cpu().numpy(), arr[f'c{i}_dx'], rtol=1e-4, atol=1e-5, err_msg=str(c))
-    after = native.launch_count(native.K_UPFIRDN2D_GENERIC) + native.launch_count(native.K_UPFIRDN2D_TILED)
+    after = native.launch_count(native.K_UPFIRDN2D_GENERIC) + native.launch_count(native.K_UPFIRDN2D_TILED) + native.launch_count(native.K_UPFIRDN2D_STREAM)
     assert after - before >= 2 * len(cases), 'the native kernels did not run'
 
 

@@ -45,8 +45,8 @@ def test_forward_matches_reference_golden_on_gpu():
     img = G(z, noise_mode='const')
     logits = D(img.detach())
     after = native.launch_counts()
-    assert after['bias_act'] > before['bias_act'] and after['upfirdn2d_tiled'] + after['upfirdn2d_generic'] > \
-        before['upfirdn2d_tiled'] + before['upfirdn2d_generic'] and after['fma_bias_act'] > before['fma_bias_act']
+    assert after['bias_act'] > before['bias_act'] and after['upfirdn2d_tiled'] + after['upfirdn2d_stream'] + after['upfirdn2d_generic'] > \
+        before['upfirdn2d_tiled'] + before['upfirdn2d_stream'] + before['upfirdn2d_generic'] and after['fma_bias_act'] > before['fma_bias_act']
     np.testing.assert_allclose(img.detach().cpu().numpy(), arr['img_train'], rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(logits.detach().cpu().numpy(), arr['logits'], rtol=1e-3, atol=1e-3)
     G.eval()
@@ -125,7 +125,7 @@ def test_aio_iteration_runs_native_and_updates_weights():
     for k in ('bias_act', 'fma_bias_act', 'alpha_composite_fwd', 'alpha_composite_bwd', 'translate_fwd', 'translate_bwd_input',
               'translate_bwd_shift'):
         assert after[k] > before[k], k
-    assert after['upfirdn2d_tiled'] > before['upfirdn2d_tiled']
+    assert after['upfirdn2d_tiled'] + after['upfirdn2d_stream'] > before['upfirdn2d_tiled'] + before['upfirdn2d_stream']
     assert t.run_iteration() == 8           # only the main phases at batch_idx 1
     torch.cuda.synchronize()
     w1 = [p.detach() for p in t.local_G_list[0].parameters()][:3]
@@ -156,7 +156,7 @@ def test_augment_pipe_on_gpu_matches_reference_golden():
                 np.testing.assert_allclose(y.cpu().numpy(), arr[f'c{c["id"]}_y'], rtol=1e-3, atol=1e-3, err_msg=f'{c} fixed={fixed}')
                 n += 1
             after = native.launch_counts()
-            assert n == 6 and after['upfirdn2d_tiled'] + after['upfirdn2d_generic'] >= before['upfirdn2d_tiled'] + before['upfirdn2d_generic'] + 4 * n
+            assert n == 6 and after['upfirdn2d_tiled'] + after['upfirdn2d_stream'] + after['upfirdn2d_generic'] >= before['upfirdn2d_tiled'] + before['upfirdn2d_stream'] + before['upfirdn2d_generic'] + 4 * n
     finally:
         AU.fixed_margin = AU.side_stream_margin = False
         GS.enabled = False
