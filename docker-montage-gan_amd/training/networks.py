@@ -67,7 +67,8 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     dcoefs = _demod_coefs(weight, styles) if demodulate else None
 
     if not fused_modconv:
-        x = x * styles.to(x.dtype).reshape(n, -1, 1, 1)
+        # modulation: native one-pass scale on the GPU (its backward is one pass as well), aten otherwise
+        x = modconv_epilogue.channel_scale(x, styles)
         x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down,
                                             padding=padding, flip_weight=flip_weight)
         if demodulate and noise is not None:
