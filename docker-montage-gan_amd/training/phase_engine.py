@@ -51,15 +51,23 @@ class GradSync:
     @torch.no_grad()
     def __call__(self, params):
         grads = [p.grad for p in params if p.grad is not None]
+        if self.world_size > 1:
+            # Every rank runs the same phase code, so the SAME parameters carry gradients everywhere (a phase that
+            # computes nothing -- global_Greg upstream -- leaves them all None and Adam skips them, as on one GPU).
+            # One tiny all-reduce checks that before the big one; a mismatch would otherwise hang or mis-add.
+            sig = torch.tensor([len(grads), sum(g.numel() for g in grads)], dtype=torch.int64, device=self._device(params))
+            lo, hi = sig.clone(), sig.clone()
+            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
+            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=self.process_group)
+            if not torch.equal(lo, hi):
+                # ranks disagree: fall back to the union, missing gradients count as zeros
+                grads = []
+                for p in params:
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                    grads.append(p.grad)
         if not grads:
             return 0
-        if self.world_size > 1:
-            # every rank must contribute the same layout: parameters without a gradient send zeros
-            grads = []
-            for p in params:
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
-                grads.append(p.grad)
         flat = torch._utils._flatten_dense_tensors(grads)
         if self.world_size > 1:
             torch.distributed.all_reduce(flat, group=self.process_group)
@@ -67,6 +75,12 @@ class GradSync:
         torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)
         torch._foreach_copy_(grads, list(torch._utils._unflatten_dense_tensors(flat, grads)))
         return flat.numel()
+
+    @staticmethod
+    def _device(params):
+        for p in params:
+            return p.device
+        return torch.device('cpu')
 
 
 class Phase(dnnlib.EasyDict):

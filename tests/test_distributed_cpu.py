@@ -47,7 +47,7 @@ def test_grad_sync_mean_nan_scrub_and_missing_grads():
     assert torch.allclose(g0[0], torch.full_like(g0[0], 1.5))         # mean of 1 and 2
     assert float(g0[1][0]) == 0.0 and torch.allclose(g0[1][1:], torch.full_like(g0[1][1:], 3.0))
     assert float(g0[2][0, 0]) == 1e5
-    assert torch.allclose(g0[3], torch.full_like(g0[3], 2.0))         # (4 + 0) / 2: the missing gradient counts as zero
+    assert torch.allclose(g0[3], torch.full_like(g0[3], 2.0))         # ranks disagreed on who has a gradient -> union, (4 + 0) / 2
 
 
 def _trainer_worker(rank, world, init_file, out_dir):
