@@ -53,7 +53,8 @@ def build_trainer(args, device, rank, world):
         if args.tiny:
             for k in ('local_G_kwargs', 'local_D_kwargs', 'global_D_kwargs'):
                 kw[k].channel_base, kw[k].channel_max = 512, 32
-        if args.channels_last:
+        if args.layout == 'nhwc':
+            importlib.import_module(f'{PKG}.torch_utils.ops.conv2d_resample').nhwc_1x1_workaround = (args.nhwc_1x1 == 'matmul')
             kw.local_G_kwargs.fp16_channels_last = True
             kw.local_D_kwargs.block_kwargs.fp16_channels_last = True
             kw.global_D_kwargs.block_kwargs.fp16_channels_last = True
@@ -70,6 +71,10 @@ def build_trainer(args, device, rank, world):
             AU.side_stream_margin, AU.fixed_margin = args.ada_margin == 'side', args.ada_margin == 'fixed'
             kw.augment_kwargs = dict(class_name='training.augment.AugmentPipe', **AU.augpipe_specs['bgc'])
             kw.augment_p, kw.ada_target = args.ada_p, None
+        if args.layout == 'nhwc':
+            importlib.import_module(f'{PKG}.torch_utils.ops.conv2d_resample').nhwc_1x1_workaround = (args.nhwc_1x1 == 'matmul')
+            kw.G_kwargs.synthesis_kwargs.fp16_channels_last = True
+            kw.D_kwargs.block_kwargs.fp16_channels_last = True
         if args.tiny:
             kw.G_kwargs.synthesis_kwargs.channel_base = kw.D_kwargs.channel_base = 512
             kw.G_kwargs.synthesis_kwargs.channel_max = kw.D_kwargs.channel_max = 32
@@ -151,7 +156,10 @@ def main():
                     help='how AugmentPipe learns its padding margin: side-stream read-back (default), clamp bound, or blocking read-back as upstream')
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark=True (MIOpen exhaustive find; minutes of warm-up on a fresh box)')
     ap.add_argument('--quiet', action='store_true')
-    ap.add_argument('--channels-last', action='store_true', help='experiment: NHWC activations in the reduced-precision blocks')
+    ap.add_argument('--layout', choices=['nhwc', 'nchw'], default='nhwc',
+                    help='memory layout of the reduced-precision blocks (the reference\'s fp16_channels_last option): nhwc keeps MIOpen\'s '
+                         'implicit-GEMM convolutions free of layout transposes; the native kernels have both')
+    ap.add_argument('--nhwc-1x1', choices=['matmul', 'conv'], default='conv', help='with nhwc: few-channel 1x1 convolutions straight to the convolution library (conv) or as the reference routes them around a cuDNN pitfall (matmul)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow)')
     ap.add_argument('--share-gpu', action='store_true', help='rehearsal only: every rank uses cuda:0')
     ap.add_argument('--marker-file', default=None, help='write clock readings at the start/end of the timed region (for cutting a rocprofv3 trace)')
@@ -271,6 +279,7 @@ def main():
             'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': workload + (' [TINY channel counts: smoke only]' if args.tiny else ''), 'global_batch': args.batch_gpu * world,
                        'batch_per_gpu': args.batch_gpu, 'layers': args.layers if args.workload == 'aio' else 1, 'resolution': args.res,
+                       'layout': f'{args.layout} in the {args.dtype} blocks (fp16_channels_last)' if args.dtype != 'fp32' else 'nchw',
                        'parallelism': f'dp{world} (one flat-buffer RCCL all-reduce per phase)',
                        'native_launches_per_step': {k: round((counts1[k] - counts0[k]) / args.steps, 1) for k in counts1 if counts1[k] - counts0[k]}},
             'roofline': roofline,

@@ -5,7 +5,9 @@
 // HBM-bound streaming op: 16-byte vector loads/stores per lane, several vectors
 // in flight per lane, grid-stride over chunks; the bias index (i / step_b) %
 // size_b is one multiply-shift per 16-byte vector when step_b is a multiple of
-// the vector width (NCHW planes), per element otherwise (NHWC / FC).
+// the vector width (NCHW planes), one 16-byte bias vector per lane when the bias
+// dimension is the contiguous one and a multiple of the vector width (NHWC), per
+// element otherwise (FC layers with odd widths).
 #include "mg_common.h"
 #include "mg_act.h"
 
@@ -25,11 +27,12 @@ template <class T> __device__ __forceinline__ uint32_t ba_bias_index(uint32_t i,
 }
 
 // VEC elements per lane per access (16 bytes, or 1 when pointers are unaligned);
-// U accesses in flight per lane.  BVEC: bias index is uniform inside one vector.
+// U accesses in flight per lane.  BVEC: 1 = bias index is uniform inside one vector, 2 = the vector's
+// elements take consecutive biases (step_b == 1, size_b % VEC == 0: channels-last), 0 = per element.
 // GT: gradient order known at compile time (0 or 1; -1 = read p.grad).  With GT fixed the loads that
 // order never needs (xref/yref/dy at order 0; b/xref/dy for the 'y'-referenced activations at order 1)
 // and their null checks disappear from the per-element code.
-template <class T, int A, int VEC, int U, bool BVEC, int GT>
+template <class T, int A, int VEC, int U, int BVEC, int GT>
 __global__ void __launch_bounds__(256) bias_act_kernel(BaArgs<T> p0)
 {
     typedef typename Acc<T>::type acc_t;
@@ -58,11 +61,14 @@ __global__ void __launch_bounds__(256) bias_act_kernel(BaArgs<T> p0)
             uint32_t vi = base + u * 256u + threadIdx.x;
             if (vi >= nvec) continue;
             acc_t bv = 0;
-            if (BVEC && p.b) bv = to_acc<T>(p.b[ba_bias_index(vi * VEC, p)]);
+            V bvec;
+            if (BVEC == 1 && p.b) bv = to_acc<T>(p.b[ba_bias_index(vi * VEC, p)]);
+            if (BVEC == 2 && p.b) bvec = *(const V*)(p.b + ba_bias_index(vi * VEC, p));
             V out;
             #pragma unroll
             for (int e = 0; e < VEC; e++) {
-                if (!BVEC && p.b) bv = to_acc<T>(p.b[ba_bias_index(vi * VEC + e, p)]);
+                if (BVEC == 0 && p.b) bv = to_acc<T>(p.b[ba_bias_index(vi * VEC + e, p)]);
+                if (BVEC == 2 && p.b) bv = to_acc<T>(bvec.v[e]);
                 acc_t xr = p.xref ? to_acc<T>(vxr[u].v[e]) : (acc_t)0;
                 acc_t yr = p.yref ? to_acc<T>(vyr[u].v[e]) : (acc_t)0;
                 acc_t dy = p.dy ? to_acc<T>(vdy[u].v[e]) : (acc_t)1;
@@ -85,7 +91,7 @@ __global__ void __launch_bounds__(256) bias_act_kernel(BaArgs<T> p0)
 }
 
 template <class T, int A, int GT>
-void launch_bias_act_g(const BaArgs<T>& p, bool aligned, bool bvec, hipStream_t stream)
+void launch_bias_act_g(const BaArgs<T>& p, bool aligned, int bvec, hipStream_t stream)
 {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int U = 4;
@@ -94,17 +100,18 @@ void launch_bias_act_g(const BaArgs<T>& p, bool aligned, bool bvec, hipStream_t 
         uint32_t nvec = p.size_x / VEC;
         uint32_t blocks = (nvec + 256u * U - 1) / (256u * U);
         blocks = blocks < 1 ? 1 : (blocks > max_blocks ? max_blocks : blocks);
-        if (bvec) hipLaunchKernelGGL((bias_act_kernel<T, A, VEC, U, true, GT>), dim3(blocks), dim3(256), 0, stream, p);
-        else      hipLaunchKernelGGL((bias_act_kernel<T, A, VEC, U, false, GT>), dim3(blocks), dim3(256), 0, stream, p);
+        if (bvec == 1)      hipLaunchKernelGGL((bias_act_kernel<T, A, VEC, U, 1, GT>), dim3(blocks), dim3(256), 0, stream, p);
+        else if (bvec == 2) hipLaunchKernelGGL((bias_act_kernel<T, A, VEC, U, 2, GT>), dim3(blocks), dim3(256), 0, stream, p);
+        else                hipLaunchKernelGGL((bias_act_kernel<T, A, VEC, U, 0, GT>), dim3(blocks), dim3(256), 0, stream, p);
     } else {
         uint32_t blocks = (p.size_x + 256u * U - 1) / (256u * U);
         blocks = blocks < 1 ? 1 : (blocks > max_blocks ? max_blocks : blocks);
-        hipLaunchKernelGGL((bias_act_kernel<T, A, 1, U, true, GT>), dim3(blocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((bias_act_kernel<T, A, 1, U, 1, GT>), dim3(blocks), dim3(256), 0, stream, p);
     }
 }
 
 template <class T, int A>
-int launch_bias_act(const BaArgs<T>& p, bool aligned, bool bvec, hipStream_t stream)
+int launch_bias_act(const BaArgs<T>& p, bool aligned, int bvec, hipStream_t stream)
 {
     // linear / relu / lrelu are what the networks run: orders 0 and 1 get their own code
     if (A <= 3 && p.grad == 0)      launch_bias_act_g<T, A, (A <= 3 ? 0 : -1)>(p, aligned, bvec, stream);
@@ -114,7 +121,7 @@ int launch_bias_act(const BaArgs<T>& p, bool aligned, bool bvec, hipStream_t str
 }
 
 template <class T>
-int dispatch_act(const BaArgs<T>& p, int act, bool aligned, bool bvec, hipStream_t s)
+int dispatch_act(const BaArgs<T>& p, int act, bool aligned, int bvec, hipStream_t s)
 {
     switch (act) {
     case 1: return launch_bias_act<T, 1>(p, aligned, bvec, s);
@@ -149,8 +156,10 @@ extern "C" int mg_bias_act(const void* x, const void* b, const void* xref, const
     int vec = 16 / es;
     if (!b) { size_b = 1; step_b = 1; }
     // inside one aligned vector the bias index is constant iff step_b is a multiple of the vector width
-    bool bvec = (b == nullptr) || (step_b % vec == 0);
-    if (!aligned) bvec = true;   // VEC = 1
+    int bvec = ((b == nullptr) || (step_b % vec == 0)) ? 1 : 0;
+    // channels-last: the bias dimension is the contiguous one -> one aligned bias vector per lane
+    if (b && step_b == 1 && size_b % vec == 0 && (((uintptr_t)b) & 15) == 0) bvec = 2;
+    if (!aligned) bvec = 1;   // VEC = 1
     int nin = 1 + (xref != nullptr) + (yref != nullptr) + (dy != nullptr);
     MgLaunchScope scope(MG_K_BIAS_ACT, (hipStream_t)stream, (double)size_x * es * (nin + 1));
     MG_DISPATCH_DTYPE(dtype, {

@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) fma_bias_act_fwd_kernel(FbArgs<T> p)
             #pragma unroll
             for (int e = 0; e < VEC; e++) {
                 float v = to_acc<T>(xin[u].v[e]) * dc;
-                if (p.noise) v += nzv[u].v[e] * ngain;
+                if (p.noise) v = __builtin_fmaf(nzv[u].v[e], ngain, v);        // one rounding, in both layouts
                 // the reference rounds the fma result to T before bias_act reads it back
                 v = to_acc<T>(from_acc<T>(v));
                 out.v[e] = from_acc<T>(ba_eval<float, A>(0, v, bb, 0.f, 0.f, 1.f, k));
@@ -350,6 +350,192 @@ int dispatch_br(const BrArgs<T>& p, int act, bool wide, uint32_t planes, hipStre
     return MG_E_ARG;
 }
 
+// ---------------------------------------------------------------------------
+// Channels-last (NHWC) variants of the epilogue and of its fused backward: the same arithmetic on the layout the
+// implicit-GEMM convolutions produce, so a bf16 block never has to be transposed back to NCHW.  One lane = one
+// 16-byte vector of VEC consecutive channels of one pixel; dcoefs and the bias arrive as small aligned vectors
+// (L1/L2 resident), the noise as one scalar per pixel.
+template <class T> struct FnArgs {
+    const T* x; const float* d; const float* noise; const T* b; T* y;
+    float alpha, gain, clamp, noise_gain;
+    const float* noise_gain_dev;
+    int64_t noise_stride_n;
+    uint32_t c, hw, cv, total_vec;
+    FastDiv cv_div, hw_div;
+};
+
+template <class T, int A>
+__global__ void __launch_bounds__(256) fma_bias_act_nhwc_fwd_kernel(FnArgs<T> p)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    struct alignas(16) V { T v[VEC]; };
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    const BaConst<float> k = {p.alpha, p.gain, p.clamp};
+    const float ngain = p.noise_gain * ((p.noise && p.noise_gain_dev) ? *p.noise_gain_dev : 1.f);
+    for (uint32_t base = blockIdx.x * (256u * FB_U); base < p.total_vec; base += gridDim.x * (256u * FB_U)) {
+        V xin[FB_U], bv[FB_U];
+        float dv[FB_U][VEC], nz[FB_U];
+        #pragma unroll
+        for (int u = 0; u < FB_U; u++) {
+            const uint32_t vi = base + u * 256u + threadIdx.x;
+            if (vi >= p.total_vec) continue;
+            xin[u] = ((const V*)p.x)[vi];
+            const uint32_t pixn = fd_div(vi, p.cv_div), cvi = vi - pixn * p.cv;
+            const uint32_t n = fd_div(pixn, p.hw_div), pix = pixn - n * p.hw;
+            nz[u] = p.noise ? p.noise[(int64_t)n * p.noise_stride_n + pix] : 0.f;
+            if (p.b) bv[u] = *(const V*)(p.b + cvi * VEC);
+            if (p.d) {
+                const f4_t* dp = (const f4_t*)(p.d + (size_t)n * p.c + cvi * VEC);
+                #pragma unroll
+                for (int q = 0; q < VEC / 4; q++) {
+                    const f4_t t = dp[q];
+                    dv[u][4 * q] = t.x; dv[u][4 * q + 1] = t.y; dv[u][4 * q + 2] = t.z; dv[u][4 * q + 3] = t.w;
+                }
+            }
+        }
+        #pragma unroll
+        for (int u = 0; u < FB_U; u++) {
+            const uint32_t vi = base + u * 256u + threadIdx.x;
+            if (vi >= p.total_vec) continue;
+            V out;
+            #pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                float v = to_acc<T>(xin[u].v[e]) * (p.d ? dv[u][e] : 1.f);
+                if (p.noise) v = __builtin_fmaf(nz[u], ngain, v);
+                v = to_acc<T>(from_acc<T>(v));                      // the reference rounds the fma result to T
+                out.v[e] = from_acc<T>(ba_eval<float, A>(0, v, p.b ? (float)to_acc<T>(bv[u].v[e]) : 0.f, 0.f, 0.f, 1.f, k));
+            }
+            ((V*)p.y)[vi] = out;
+        }
+    }
+}
+
+template <class T> struct BnArgs {
+    const T* dy; const T* yref; const T* x; const float* d; const float* noise; T* dx;
+    float* gd; float* gb; float* gs;       // gd [N*C]; gb [N*C] (per-sample partial sums); gs [1]
+    float alpha, gain, clamp;
+    int64_t noise_stride_n;
+    uint32_t c, hw, cv, slices, slice_pix;
+};
+
+// One workgroup = one slice of the pixels of one sample.  256 % cv == 0, so a lane keeps the same channel vector
+// for the whole slice and its VEC running sums per reduction stay in registers; they meet in LDS at the end.
+template <class T, int A>
+__global__ void __launch_bounds__(256) bwd_fused_nhwc_kernel(BnArgs<T> p)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    struct alignas(16) V { T v[VEC]; };
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    const BaConst<float> k = {p.alpha, p.gain, p.clamp};
+    const uint32_t n = blockIdx.x / p.slices, slice = blockIdx.x - n * p.slices;
+    const uint32_t pl = threadIdx.x / p.cv, cvi = threadIdx.x - pl * p.cv, ppi = 256u / p.cv;
+    const uint32_t lo = slice * p.slice_pix, hi = min(p.hw, lo + p.slice_pix);
+    const size_t base = (size_t)n * p.hw * p.c + cvi * VEC;
+    const float* nzp = p.noise ? p.noise + (int64_t)n * p.noise_stride_n : nullptr;
+    float dv[VEC];
+    #pragma unroll
+    for (int e = 0; e < VEC; e++) dv[e] = 1.f;
+    if (p.d) {
+        const f4_t* dp = (const f4_t*)(p.d + (size_t)n * p.c + cvi * VEC);
+        #pragma unroll
+        for (int q = 0; q < VEC / 4; q++) { const f4_t t = dp[q]; dv[4 * q] = t.x; dv[4 * q + 1] = t.y; dv[4 * q + 2] = t.z; dv[4 * q + 3] = t.w; }
+    }
+    float s_gd[VEC], s_gb[VEC], s_gs = 0.f;
+    #pragma unroll
+    for (int e = 0; e < VEC; e++) { s_gd[e] = 0.f; s_gb[e] = 0.f; }
+    constexpr int BU = 4;
+    for (uint32_t pix0 = lo + pl; pix0 < hi; pix0 += ppi * BU) {
+        V vdy[BU], vy[BU], vx[BU];
+        float nz[BU];
+        #pragma unroll
+        for (int u = 0; u < BU; u++) {
+            const uint32_t pix = pix0 + u * ppi;
+            if (pix >= hi) continue;
+            const size_t off = base + (size_t)pix * p.c;
+            vdy[u] = *(const V*)(p.dy + off);
+            if (p.yref) vy[u] = *(const V*)(p.yref + off);
+            if (p.x) vx[u] = *(const V*)(p.x + off);
+            nz[u] = nzp ? nzp[pix] : 0.f;
+        }
+        #pragma unroll
+        for (int u = 0; u < BU; u++) {
+            const uint32_t pix = pix0 + u * ppi;
+            if (pix >= hi) continue;
+            V out;
+            float srow = 0.f;
+            #pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                float g = to_acc<T>(vdy[u].v[e]);
+                if (p.yref) g = ba_eval<float, A>(1, g, 0.f, 0.f, to_acc<T>(vy[u].v[e]), 1.f, k);
+                const float gq = to_acc<T>(from_acc<T>(g));        // autograd materialises dpre in T
+                out.v[e] = from_acc<T>(gq * dv[e]);
+                s_gb[e] += gq;
+                if (p.x) s_gd[e] += gq * to_acc<T>(vx[u].v[e]);
+                srow += gq;
+            }
+            if (nzp) s_gs += srow * nz[u];
+            *(V*)(p.dx + base + (size_t)pix * p.c) = out;
+        }
+    }
+    __shared__ float red[256][VEC + 1];
+    const uint32_t C = p.c;
+    if (p.gd) {
+        #pragma unroll
+        for (int e = 0; e < VEC; e++) red[threadIdx.x][e] = s_gd[e];
+        __syncthreads();
+        for (uint32_t ch = threadIdx.x; ch < C; ch += 256u) {
+            const uint32_t cq = ch / VEC, e = ch - cq * VEC;
+            float t = 0.f;
+            for (uint32_t q = 0; q < ppi; q++) t += red[q * p.cv + cq][e];
+            atomicAdd(p.gd + (size_t)n * C + ch, t);
+        }
+        __syncthreads();
+    }
+    if (p.gb) {
+        #pragma unroll
+        for (int e = 0; e < VEC; e++) red[threadIdx.x][e] = s_gb[e];
+        __syncthreads();
+        for (uint32_t ch = threadIdx.x; ch < C; ch += 256u) {
+            const uint32_t cq = ch / VEC, e = ch - cq * VEC;
+            float t = 0.f;
+            for (uint32_t q = 0; q < ppi; q++) t += red[q * p.cv + cq][e];
+            atomicAdd(p.gb + (size_t)n * C + ch, t);
+        }
+    }
+    if (p.gs) {
+        #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s_gs += __shfl_down(s_gs, o, 64);
+        __shared__ float red_s[4];
+        if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = s_gs;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(p.gs, red_s[0] + red_s[1] + red_s[2] + red_s[3]);
+    }
+}
+
+template <class T, int A>
+void launch_nhwc(const FnArgs<T>* f, const BnArgs<T>* b, uint32_t n, hipStream_t s)
+{
+    if (f) {
+        uint32_t blocks = (f->total_vec + 256u * FB_U - 1) / (256u * FB_U);
+        if (blocks > 256u * 8u) blocks = 256u * 8u;
+        hipLaunchKernelGGL((fma_bias_act_nhwc_fwd_kernel<T, A>), dim3(blocks), dim3(256), 0, s, *f);
+    } else {
+        hipLaunchKernelGGL((bwd_fused_nhwc_kernel<T, A>), dim3(n * b->slices), dim3(256), 0, s, *b);
+    }
+}
+
+template <class T>
+int dispatch_nhwc(const FnArgs<T>* f, const BnArgs<T>* b, int act, uint32_t n, hipStream_t s)
+{
+    switch (act) {
+    case 1: launch_nhwc<T, 1>(f, b, n, s); return MG_OK;
+    case 2: launch_nhwc<T, 2>(f, b, n, s); return MG_OK;
+    case 3: launch_nhwc<T, 3>(f, b, n, s); return MG_OK;
+    }
+    mg_set_error("channels-last epilogue: only linear / relu / lrelu are fused (activation %d)", act);
+    return MG_E_ARG;
+}
+
 } // namespace
 
 extern "C" int mg_fma_bias_act(const void* x, const float* d, const float* noise, const void* b, void* y, int dtype,
@@ -472,4 +658,72 @@ extern "C" int mg_bwd_fused(const void* dy, const void* yref, const void* x, con
     });
     if (rc) return rc;
     return mg_check_launch(MG_K_BWD_FUSED, "bwd_fused");
+}
+
+extern "C" int mg_fma_bias_act_nhwc(const void* x, const float* d, const float* noise, const void* b, void* y, int dtype,
+                                    int act, float alpha, float gain, float clamp, float noise_gain, const float* noise_gain_dev,
+                                    int64_t noise_stride_n, int32_t n, int32_t c, int32_t hw, void* stream)
+{
+    MG_REQUIRE(x && y, "x must reside on the device");
+    MG_REQUIRE(dtype == MG_F32 || dtype == MG_F16 || dtype == MG_BF16, "fma_bias_act_nhwc: unsupported dtype %d", dtype);
+    MG_REQUIRE(n >= 0 && c >= 1 && hw >= 1, "fma_bias_act_nhwc: bad shape");
+    int64_t total = (int64_t)n * c * hw;
+    MG_REQUIRE(total <= INT32_MAX, "x is too large");
+    if (total == 0) return MG_OK;
+    int es = mg_dtype_size(dtype), vec = 16 / es;
+    MG_REQUIRE(c % vec == 0, "fma_bias_act_nhwc: channels must be a multiple of %d", vec);
+    MG_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)d | (uintptr_t)b) & 15) == 0, "fma_bias_act_nhwc: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    MgLaunchScope scope(MG_K_FMA_BIAS_ACT, s, 2.0 * total * es);
+    int rc = MG_OK;
+    MG_DISPATCH_DTYPE(dtype, {
+        if (sizeof(T) == 8) break;
+        FnArgs<T> p;
+        p.x = (const T*)x; p.d = d; p.noise = noise; p.b = (const T*)b; p.y = (T*)y;
+        p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_gain = noise_gain; p.noise_gain_dev = noise_gain_dev; p.noise_stride_n = noise_stride_n;
+        p.c = (uint32_t)c; p.hw = (uint32_t)hw; p.cv = (uint32_t)(c / vec); p.total_vec = (uint32_t)(total / vec);
+        p.cv_div = make_fastdiv(p.cv); p.hw_div = make_fastdiv(p.hw);
+        rc = dispatch_nhwc<T>(&p, nullptr, act, (uint32_t)n, s);
+    });
+    if (rc) return rc;
+    return mg_check_launch(MG_K_FMA_BIAS_ACT, "fma_bias_act_nhwc");
+}
+
+extern "C" int mg_bwd_fused_nhwc(const void* dy, const void* yref, const void* x, const float* d, const float* noise,
+                                 void* dx, float* gd, float* gb_partial, float* gs, int dtype, int act, float alpha, float gain,
+                                 float clamp, int64_t noise_stride_n, int32_t n, int32_t c, int32_t hw, void* stream)
+{
+    MG_REQUIRE(dy && dx, "dy must reside on the device");
+    MG_REQUIRE(dtype == MG_F32 || dtype == MG_F16 || dtype == MG_BF16, "bwd_fused_nhwc: unsupported dtype %d", dtype);
+    MG_REQUIRE(n >= 0 && c >= 1 && hw >= 1, "bwd_fused_nhwc: bad shape");
+    MG_REQUIRE(!gd || x, "bwd_fused_nhwc: gd needs x");
+    MG_REQUIRE(!gs || noise, "bwd_fused_nhwc: gs needs noise");
+    int64_t total = (int64_t)n * c * hw;
+    MG_REQUIRE(total <= INT32_MAX, "x is too large");
+    if (total == 0) return MG_OK;
+    int es = mg_dtype_size(dtype), vec = 16 / es;
+    MG_REQUIRE(c % vec == 0 && c / vec <= 256 && 256 % (c / vec) == 0, "bwd_fused_nhwc: channels/%d must divide 256", vec);
+    MG_REQUIRE((((uintptr_t)dy | (uintptr_t)yref | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)d) & 15) == 0, "bwd_fused_nhwc: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    int passes = 2 + (yref != nullptr) + (x != nullptr);
+    MgLaunchScope scope(MG_K_BWD_FUSED, s, (double)passes * total * es);
+    int rc = MG_OK;
+    MG_DISPATCH_DTYPE(dtype, {
+        if (sizeof(T) == 8) break;
+        BnArgs<T> p;
+        p.dy = (const T*)dy; p.yref = (const T*)yref; p.x = (const T*)x; p.d = d; p.noise = gs ? noise : nullptr; p.dx = (T*)dx;
+        p.gd = gd; p.gb = gb_partial; p.gs = gs; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_stride_n = noise_stride_n;
+        p.c = (uint32_t)c; p.hw = (uint32_t)hw; p.cv = (uint32_t)(c / vec);
+        const uint32_t ppi = 256u / p.cv, unit = ppi * 4u;            // pixels per round of 4 vectors in flight
+        uint32_t per = unit * 4u;                                     // about 16 vectors per lane per slice
+        uint32_t slices = (p.hw + per - 1) / per;
+        if (slices > 64) slices = 64;
+        if (slices < 1) slices = 1;
+        per = ((p.hw + slices - 1) / slices + unit - 1) / unit * unit;
+        slices = (p.hw + per - 1) / per;
+        p.slices = slices; p.slice_pix = per;
+        rc = dispatch_nhwc<T>(nullptr, &p, act, (uint32_t)n, s);
+    });
+    if (rc) return rc;
+    return mg_check_launch(MG_K_BWD_FUSED, "bwd_fused_nhwc");
 }

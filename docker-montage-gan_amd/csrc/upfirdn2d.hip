@@ -426,7 +426,207 @@ bool try_stream(const UfParams& p, hipStream_t s)
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// Channels-last kernel: dense NHWC input and output (the layout MIOpen's implicit-GEMM convolutions run in
+// natively), filters up to 4x4, up/down in {1,2}.  One lane owns ONE 16-byte channel vector of MX adjacent
+// output pixels and walks down a chunk of output rows MY at a time; neighbouring lanes hold neighbouring
+// channel vectors, then neighbouring pixels, so every access of a wave is one contiguous run of the row.
+// No LDS: the FW-1 / FH-1 overlaps between lanes and between consecutive row blocks are served by L1/L2.
+// The polyphase structure is the compile-time logic of the tiled kernel (PX/PY = phase of the lane origin).
+// All global accesses go through range-checked buffer descriptors; a lane outside the image swaps its
+// offset for one beyond the buffer (loads return 0, stores are dropped), so there are no border branches.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+template <class T> struct NhwcVec { static constexpr int VEC = 16 / (int)sizeof(T); };
+
+template <class T> __device__ __forceinline__ void nhwc_unpack(const u32x4_t& r, float (&v)[NhwcVec<T>::VEC])
+{
+    // (copy the lanes to scalars first: __builtin_bit_cast applied directly to a vector element reads lane 0)
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+    if constexpr (sizeof(T) == 4) {
+        #pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = __builtin_bit_cast(float, w[q]);
+    } else {
+        #pragma unroll
+        for (int q = 0; q < 4; q++) { v[2 * q] = raw16_to_f32<T>(w[q] & 0xffffu); v[2 * q + 1] = raw16_to_f32<T>(w[q] >> 16); }
+    }
+}
+
+template <class T> __device__ __forceinline__ u32x4_t nhwc_pack(const float (&v)[NhwcVec<T>::VEC])
+{
+    u32x4_t r;
+    unsigned w[4];
+    if constexpr (sizeof(T) == 4) {
+        #pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = __builtin_bit_cast(unsigned, v[q]);
+    } else {
+        #pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = f32_to_raw16<T>(v[2 * q]) | (f32_to_raw16<T>(v[2 * q + 1]) << 16);
+    }
+    r.x = w[0]; r.y = w[1]; r.z = w[2]; r.w = w[3];
+    return r;
+}
+
+struct NhwcGrid { uint32_t cv, gx, nchunks, total, rows_per_chunk; FastDiv cv_div, gx_div, chunk_div; };
+
+template <class T, int UP, int DN, int PX, int PY, int MX, int MY>
+__global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
+{
+    constexpr int VEC = NhwcVec<T>::VEC, FW = 4, FH = 4, ES = (int)sizeof(T);
+    constexpr int RX = (PX + (MX - 1) * DN + FW - 1) / UP + 1, RY = (PY + (MY - 1) * DN + FH - 1) / UP + 1;
+    constexpr int LANE_DX = MX * DN / UP, LANE_DY = MY * DN / UP;
+    static_assert((MX * DN) % UP == 0 && (MY * DN) % UP == 0, "micro tile must span whole input samples");
+    constexpr unsigned BAD = 0x80000000u;
+
+    float ft[FH][FW];
+    #pragma unroll
+    for (int ky = 0; ky < FH; ky++)
+        #pragma unroll
+        for (int kx = 0; kx < FW; kx++) {
+            float v = 0.f;
+            if (kx < p.f_w && ky < p.f_h)
+                v = p.f[(p.flip ? ky : p.f_h - 1 - ky) * p.fs_h + (p.flip ? kx : p.f_w - 1 - kx) * p.fs_w];
+            ft[ky][kx] = v * p.gain;
+        }
+
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= g.total) return;
+    const uint32_t t1 = fd_div(t, g.cv_div), cvi = t - t1 * g.cv;
+    const uint32_t t2 = fd_div(t1, g.gx_div), gxi = t1 - t2 * g.gx;
+    const uint32_t n = fd_div(t2, g.chunk_div), chunk = t2 - n * g.nchunks;
+
+    const uint32_t in_bytes = (uint32_t)((int64_t)p.n * p.c * p.in_h * p.in_w * ES);
+    const uint32_t out_bytes = (uint32_t)((int64_t)p.n * p.c * p.out_h * p.out_w * ES);
+    const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)in_bytes, 0x00020000);
+    const auto rout = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)out_bytes, 0x00020000);
+
+    const int pix_bytes = p.c * ES;
+    const int ox0 = (int)gxi * MX;
+    const int ix0 = mg_floor_div(UP - 1 - p.padx0, UP) + (int)gxi * LANE_DX;        // first input column of the lane window
+    int col_off[RX];                                                                // byte offset inside a row, or -1
+    #pragma unroll
+    for (int rx = 0; rx < RX; rx++) {
+        const int ix = ix0 + rx;
+        col_off[rx] = (ix >= 0 && ix < p.in_w) ? ix * pix_bytes + (int)cvi * 16 : -1;
+    }
+    unsigned st_off[MX];
+    #pragma unroll
+    for (int i = 0; i < MX; i++) st_off[i] = (ox0 + i < p.out_w) ? (unsigned)((ox0 + i) * pix_bytes + (int)cvi * 16) : BAD;
+    const int in_pitch = p.in_w * pix_bytes, out_pitch = p.out_w * pix_bytes;
+    const int oy_begin = (int)(chunk * g.rows_per_chunk), oy_end = min(p.out_h, oy_begin + (int)g.rows_per_chunk);
+    const int iy_base = mg_floor_div(UP - 1 - p.pady0, UP);
+
+    for (int oy0 = oy_begin; oy0 < oy_end; oy0 += MY) {
+        const int iy0 = iy_base + oy0 / MY * LANE_DY;
+        float acc[MY][MX][VEC];
+        #pragma unroll
+        for (int j = 0; j < MY; j++)
+            #pragma unroll
+            for (int i = 0; i < MX; i++)
+                #pragma unroll
+                for (int e = 0; e < VEC; e++) acc[j][i][e] = 0.f;
+
+        // rows are requested RG at a time (at most 16 vectors = 64 VGPRs in flight), then consumed
+        constexpr int RG = (RX * RY <= 16) ? RY : (16 / RX);
+        #pragma unroll
+        for (int ry0 = 0; ry0 < RY; ry0 += RG) {
+            u32x4_t raw[RG][RX];
+            #pragma unroll
+            for (int r = 0; r < RG; r++) {
+                const int ry = ry0 + r;
+                if (ry >= RY) break;
+                const int iy = iy0 + ry;
+                const bool row_ok = iy >= 0 && iy < p.in_h;
+                const int row_off = ((int)n * p.in_h + iy) * in_pitch;
+                #pragma unroll
+                for (int rx = 0; rx < RX; rx++) {
+                    const unsigned off = (row_ok && col_off[rx] >= 0) ? (unsigned)(row_off + col_off[rx]) : BAD;
+                    raw[r][rx] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
+                }
+            }
+            #pragma unroll
+            for (int r = 0; r < RG; r++) {
+                const int ry = ry0 + r;
+                if (ry >= RY) break;
+                float row[RX][VEC];
+                #pragma unroll
+                for (int rx = 0; rx < RX; rx++) nhwc_unpack<T>(raw[r][rx], row[rx]);
+                #pragma unroll
+                for (int j = 0; j < MY; j++) {
+                    const int my = PY + j * DN;
+                    const int iy_first = my / UP;
+                    const int fy_first = (iy_first + 1) * UP - my - 1;
+                    const int ky = fy_first + (ry - iy_first) * UP;
+                    if (ry < iy_first || ky >= FH) continue;
+                    #pragma unroll
+                    for (int i = 0; i < MX; i++) {
+                        const int mx = PX + i * DN;
+                        const int ix_first = mx / UP;
+                        const int fx_first = (ix_first + 1) * UP - mx - 1;
+                        #pragma unroll
+                        for (int kx = fx_first, rx = ix_first; kx < FW; kx += UP, rx++)
+                            #pragma unroll
+                            for (int e = 0; e < VEC; e++) acc[j][i][e] = __builtin_fmaf(row[rx][e], ft[ky][kx], acc[j][i][e]);
+                    }
+                }
+            }
+        }
+        #pragma unroll
+        for (int j = 0; j < MY; j++) {
+            const int oy = oy0 + j;
+            const unsigned row_off = (unsigned)(((int)n * p.out_h + oy) * out_pitch);
+            #pragma unroll
+            for (int i = 0; i < MX; i++) {
+                const unsigned off = (oy < p.out_h && st_off[i] != BAD) ? row_off + st_off[i] : BAD;
+                __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack<T>(acc[j][i]), rout, off, 0, 0);
+            }
+        }
+    }
+}
+
+template <class T, int UP, int DN, int PX, int PY>
+void launch_nhwc_phase(const UfParams& p, hipStream_t s)
+{
+    constexpr int VEC = NhwcVec<T>::VEC, MX = (UP == 2 ? 2 : 1), MY = 4;
+    NhwcGrid g;
+    g.cv = (uint32_t)(p.c / VEC);
+    g.gx = (uint32_t)((p.out_w + MX - 1) / MX);
+    // rows per chunk: a multiple of MY; 32 output rows keep the inter-chunk halo small while leaving >= 8 workgroups per CU on the big layers
+    g.rows_per_chunk = 32;
+    g.nchunks = (uint32_t)((p.out_h + (int)g.rows_per_chunk - 1) / (int)g.rows_per_chunk);
+    g.total = (uint32_t)p.n * g.nchunks * g.gx * g.cv;
+    g.cv_div = make_fastdiv(g.cv); g.gx_div = make_fastdiv(g.gx); g.chunk_div = make_fastdiv(g.nchunks);
+    hipLaunchKernelGGL((upfirdn2d_nhwc<T, UP, DN, PX, PY, MX, MY>), dim3((g.total + 255u) / 256u), dim3(256), 0, s, p, g);
+}
+
+template <class T>
+bool try_nhwc(const UfParams& p, hipStream_t s)
+{
+    constexpr int VEC = NhwcVec<T>::VEC;
+    const int64_t C = p.c;
+    const bool dense = p.c > 1 && p.xs_c == 1 && p.xs_w == C && p.xs_h == C * p.in_w && p.xs_n == C * p.in_w * p.in_h &&
+                       p.ys_c == 1 && p.ys_w == C && p.ys_h == C * p.out_w && p.ys_n == C * p.out_w * p.out_h;
+    if (!dense || p.c % VEC != 0 || p.f_w > 4 || p.f_h > 4) return false;
+    if ((((uintptr_t)p.x | (uintptr_t)p.y) & 15) != 0) return false;
+    if (p.upx != p.upy || p.downx != p.downy) return false;
+    const int64_t lim = (1ll << 31) - 64;
+    if (C * p.n * p.in_h * p.in_w * (int64_t)sizeof(T) >= lim || C * p.n * p.out_h * p.out_w * (int64_t)sizeof(T) >= lim) return false;
+    if ((int64_t)p.n * ((p.out_h + 31) / 32) * p.out_w * (C / VEC) >= (int64_t)UINT32_MAX / 2) return false;
+    const int px = ((p.upx - 1 - p.padx0) % p.upx + p.upx) % p.upx, py = ((p.upy - 1 - p.pady0) % p.upy + p.upy) % p.upy;
+    if (p.upx == 1 && p.downx == 1) { launch_nhwc_phase<T, 1, 1, 0, 0>(p, s); return true; }
+    if (p.upx == 1 && p.downx == 2) { launch_nhwc_phase<T, 1, 2, 0, 0>(p, s); return true; }
+    if (p.upx == 2 && p.downx == 1) {
+        if (px == 0 && py == 0) launch_nhwc_phase<T, 2, 1, 0, 0>(p, s);
+        if (px == 1 && py == 0) launch_nhwc_phase<T, 2, 1, 1, 0>(p, s);
+        if (px == 0 && py == 1) launch_nhwc_phase<T, 2, 1, 0, 1>(p, s);
+        if (px == 1 && py == 1) launch_nhwc_phase<T, 2, 1, 1, 1>(p, s);
+        return true;
+    }
+    return false;
+}
+
 static thread_local bool g_last_was_stream = false;
+static thread_local bool g_last_was_nhwc = false;
 
 // Returns true when a tiled (or the streaming) specialisation took the call.
 template <class T>
@@ -435,7 +635,10 @@ bool try_tiled(const UfParams& p, hipStream_t s)
     const bool dense = p.xs_w == 1 && p.xs_h == p.in_w && p.xs_c == (int64_t)p.in_h * p.in_w &&
                        p.xs_n == (int64_t)p.c * p.in_h * p.in_w && p.ys_w == 1 && p.ys_h == p.out_w &&
                        p.ys_c == (int64_t)p.out_h * p.out_w && p.ys_n == (int64_t)p.c * p.out_h * p.out_w;
-    if (!dense) return false;
+    if (!dense) {
+        if (try_nhwc<T>(p, s)) { g_last_was_nhwc = true; return true; }
+        return false;
+    }
     if (sizeof(T) <= 4 && try_stream<T>(p, s)) { g_last_was_stream = true; return true; }
     const int ux = p.upx, uy = p.upy, dx = p.downx, dy = p.downy, fw = p.f_w, fh = p.f_h;
 #define UF_CASE(UX, UY, DX, DY, FW_, FH_, MX_, MY_)                                                       \
@@ -493,7 +696,7 @@ extern "C" int mg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
     bool tiled = false;
     {
         MgLaunchScope scope(MG_K_UPFIRDN2D_TILED, s, (double)(xn + yn) * es);
-        g_last_was_stream = false;
+        g_last_was_stream = false; g_last_was_nhwc = false;
         switch (dtype) {
         case MG_F32:  tiled = try_tiled<float>(p, s); break;
         case MG_F16:  tiled = try_tiled<mg_half>(p, s); break;
@@ -502,8 +705,9 @@ extern "C" int mg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
         }
         if (!tiled) scope.kid = -1;
         else if (g_last_was_stream) scope.kid = MG_K_UPFIRDN2D_STREAM;
+        else if (g_last_was_nhwc) scope.kid = MG_K_UPFIRDN2D_NHWC;
     }
-    if (tiled) return mg_check_launch(g_last_was_stream ? MG_K_UPFIRDN2D_STREAM : MG_K_UPFIRDN2D_TILED, "upfirdn2d");
+    if (tiled) return mg_check_launch(g_last_was_stream ? MG_K_UPFIRDN2D_STREAM : g_last_was_nhwc ? MG_K_UPFIRDN2D_NHWC : MG_K_UPFIRDN2D_TILED, "upfirdn2d");
 
     MgLaunchScope scope(MG_K_UPFIRDN2D_GENERIC, s, (double)(xn + yn) * es);
     uint32_t total = (uint32_t)yn;

@@ -129,20 +129,26 @@ def _bias_act_cuda(dim=1, act='linear', alpha=None, gain=None, clamp=None):
             dy = dy.contiguous(memory_format=ctx.memory_format)
             x, b, y = ctx.saved_tensors
             dx = db = None
-            # Plain first-order backward of the network layers (NCHW, bias on dim 1, piecewise-linear activation):
+            # Plain first-order backward of the network layers (NCHW or NHWC, bias on dim 1, piecewise-linear activation):
             # ONE native pass writes dx and leaves sum(dx) per channel in a float32 accumulator, instead of the
             # gradient kernel followed by a separate reduction over dx (upstream :186-196).
             if (ctx.needs_input_grad[1] and not torch.is_grad_enabled() and not is_identity and idx <= 3 and dim == 1
-                    and dy.ndim == 4 and ctx.memory_format == torch.contiguous_format and dy.dtype != torch.float64 and dy.numel() > 0):
+                    and dy.ndim == 4 and dy.dtype != torch.float64 and dy.numel() > 0):
                 n, c, h, w = dy.shape
-                dx = torch.empty_like(dy)
-                acc = torch.zeros([c], dtype=torch.float32, device=dy.device)
-                with torch.cuda.device(dy.device):
-                    native.check(native.lib().mg_bwd_fused(
-                        native.ptr(dy), native.ptr(y if y.numel() else None), native.ptr(None), native.ptr(None), native.ptr(None),
-                        native.ptr(dx), native.ptr(None), native.ptr(acc), native.ptr(None), native.dtype_code(dy.dtype), idx,
-                        alpha, gain, clamp, 0, n, c, h * w, native.stream_ptr(dy.device)))
-                return (dx if ctx.needs_input_grad[0] else None), acc.to(dy.dtype)
+                vec = 16 // dy.element_size()
+                nhwc = ctx.memory_format == torch.channels_last
+                if not nhwc or (c % vec == 0 and c // vec <= 256 and 256 % (c // vec) == 0):
+                    dx = torch.empty_like(dy)
+                    # the channels-last kernel leaves per-sample partial sums [N, C]
+                    acc = torch.zeros([n * c if nhwc else c], dtype=torch.float32, device=dy.device)
+                    with torch.cuda.device(dy.device):
+                        bwd = native.lib().mg_bwd_fused_nhwc if nhwc else native.lib().mg_bwd_fused
+                        native.check(bwd(
+                            native.ptr(dy), native.ptr(y if y.numel() else None), native.ptr(None), native.ptr(None), native.ptr(None),
+                            native.ptr(dx), native.ptr(None), native.ptr(acc), native.ptr(None), native.dtype_code(dy.dtype), idx,
+                            alpha, gain, clamp, 0, n, c, h * w, native.stream_ptr(dy.device)))
+                    db = acc.reshape(n, c).sum(0) if nhwc else acc
+                    return (dx if ctx.needs_input_grad[0] else None), db.to(dy.dtype)
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
                 dx = dy if is_identity else BiasActCudaGrad.apply(dy, x, b, y)
             if ctx.needs_input_grad[1]:

@@ -23,6 +23,9 @@ from .upfirdn2d import _get_filter_size
 from .upfirdn2d import _parse_padding
 
 
+nhwc_1x1_workaround = True      # see _conv2d_wrapper
+
+
 def _get_weight_shape(w):
     shape = [int(sz) for sz in w.shape]
     misc.assert_shape(w, shape)
@@ -34,10 +37,10 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
     oc, icg, kh, kw = _get_weight_shape(w)
     if not flip_weight and (kh > 1 or kw > 1):
         w = w.flip([2, 3])
-    # channels_last 1x1 convolutions with few channels are a plain (batched) matmul; the reference
-    # routes them around a cuDNN 8.0.5 pitfall (:40-52) -- kept because MIOpen has no tuned NHWC
-    # solver for <64 channel 1x1 either, and a [oc, ic] @ [ic, HW] GEMM is what the op is.
-    if kw == 1 and kh == 1 and stride == 1 and padding in [0, [0, 0], (0, 0)] and not transpose:
+    # channels_last 1x1 convolutions with few channels: the reference routes them around a cuDNN 8.0.5 pitfall
+    # (:40-52) as a batched matmul / an NCHW convolution.  `nhwc_1x1_workaround` keeps that routing (default);
+    # switched off, the convolution library gets the NHWC tensor directly.
+    if nhwc_1x1_workaround and kw == 1 and kh == 1 and stride == 1 and padding in [0, [0, 0], (0, 0)] and not transpose:
         if x.stride()[1] == 1 and min(oc, icg) < 64:
             if oc <= 4 and groups == 1:
                 n, _, h, ww = x.shape

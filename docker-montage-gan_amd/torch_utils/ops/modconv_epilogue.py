@@ -40,6 +40,16 @@ def _epilogue_ref(x, dcoefs, noise, b, act, alpha, gain, clamp):
     return _ba.bias_act(x, b.to(x.dtype) if b is not None else None, act=act, alpha=alpha, gain=gain, clamp=clamp)
 
 
+def _is_nhwc(x):
+    """Dense channels-last 4-D tensor the NHWC kernels accept (channel count a multiple of the 16-byte vector that
+    divides 256 vectors, so the fused backward can keep one channel vector per lane)."""
+    if x.ndim != 4 or x.is_contiguous() or not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    vec = 16 // x.element_size()
+    c = x.shape[1]
+    return c % vec == 0 and c // vec <= 256 and 256 % (c // vec) == 0
+
+
 _cache = dict()
 
 
@@ -60,7 +70,9 @@ def _epilogue_hip(act, alpha, gain, clamp):
         @staticmethod
         def forward(ctx, x, dcoefs, noise, strength, b):
             n, c, h, w = x.shape
-            x = x.contiguous()
+            nhwc = _is_nhwc(x)
+            if not nhwc:
+                x = x.contiguous()
             # the reference multiplies by dcoefs.to(x.dtype): keep that rounding, then widen for the kernel
             d32 = dcoefs.detach().to(x.dtype).to(torch.float32).contiguous() if dcoefs is not None else None
             nz32, nz_stride, s32 = None, 0, None
@@ -71,16 +83,18 @@ def _epilogue_hip(act, alpha, gain, clamp):
                 if strength is not None:        # stays on the device: the kernel reads the scalar itself
                     s32 = strength.detach().to(torch.float32).reshape(1).contiguous()
             bb = b.detach().to(x.dtype).contiguous() if b is not None else None
-            y = torch.empty_like(x)
+            y = torch.empty_like(x)         # keeps the (dense) layout of x
             if x.numel():
                 with torch.cuda.device(x.device):
-                    native.check(native.lib().mg_fma_bias_act(
+                    fwd = native.lib().mg_fma_bias_act_nhwc if nhwc else native.lib().mg_fma_bias_act
+                    native.check(fwd(
                         native.ptr(x), native.ptr(d32), native.ptr(nz32), native.ptr(bb), native.ptr(y),
                         native.dtype_code(x.dtype), idx, alpha, gain, clamp, 1.0, native.ptr(s32), nz_stride, n, c, h * w,
                         native.stream_ptr(x.device)))
             ctx.save_for_backward(x, dcoefs if dcoefs is not None else null, y, nz32 if nz32 is not None else null,
                                   s32 if s32 is not None else null)
             ctx.has = (dcoefs is not None, noise is not None, b is not None, strength is not None)
+            ctx.nhwc = nhwc
             ctx.noise_meta = None if noise is None else (noise.dtype, noise.shape, nz_stride)
             ctx.b_dtype = None if b is None else b.dtype
             ctx.s_dtype = None if strength is None else strength.dtype
@@ -93,7 +107,8 @@ def _epilogue_hip(act, alpha, gain, clamp):
             has_d, has_nz, has_b, has_s = ctx.has
             nz_gain = s32.reshape([]) if has_s else 1.0
             need = ctx.needs_input_grad          # x, dcoefs, noise, strength, b
-            dy = dy.contiguous()
+            nhwc = ctx.nhwc
+            dy = dy.contiguous(memory_format=torch.channels_last) if nhwc else dy.contiguous()
             ident = (act == 'linear' and gain == 1 and clamp < 0)
             if torch.is_grad_enabled():
                 # differentiable assembly (create_graph=True)
@@ -117,19 +132,21 @@ def _epilogue_hip(act, alpha, gain, clamp):
             want_gs = has_nz and has_s and need[3]
             want_gn = has_nz and need[2]
             dx = torch.empty_like(x)
-            acc = torch.zeros([n * c + c + 1], dtype=torch.float32, device=x.device)
-            gd_a, gb_a, gs_a = acc[:n * c], acc[n * c:n * c + c], acc[n * c + c:]
+            nb = n * c if nhwc else c       # the NHWC kernel leaves per-sample partial bias sums
+            acc = torch.zeros([n * c + nb + 4], dtype=torch.float32, device=x.device)
+            gd_a, gb_a, gs_a = acc[:n * c], acc[n * c:n * c + nb], acc[n * c + nb:n * c + nb + 1]
             stride = ctx.noise_meta[2] if has_nz else 0
             d32 = dcoefs.to(x.dtype).to(torch.float32).contiguous() if has_d else None
             if x.numel():
                 with torch.cuda.device(x.device):
-                    native.check(native.lib().mg_bwd_fused(
+                    bwd = native.lib().mg_bwd_fused_nhwc if nhwc else native.lib().mg_bwd_fused
+                    native.check(bwd(
                         native.ptr(dy), native.ptr(None if ident else y), native.ptr(x if want_gd else None), native.ptr(d32),
                         native.ptr(nz32 if want_gs else None), native.ptr(dx), native.ptr(gd_a if want_gd else None),
                         native.ptr(gb_a if want_gb else None), native.ptr(gs_a if want_gs else None),
                         native.dtype_code(x.dtype), idx, alpha, gain, clamp, stride, n, c, h * w, native.stream_ptr(x.device)))
             gd = gd_a.reshape(n, c).to(dcoefs.dtype) if want_gd else None
-            gb = gb_a.to(ctx.b_dtype) if want_gb else None
+            gb = (gb_a.reshape(n, c).sum(0) if nhwc else gb_a).to(ctx.b_dtype) if want_gb else None
             gs = gs_a.reshape([]).to(ctx.s_dtype) if want_gs else None
             gn = None
             if want_gn:         # a caller-scaled noise tensor that wants its own gradient: not the hot path
@@ -154,7 +171,7 @@ def modconv_epilogue(x, dcoefs=None, noise=None, b=None, act='lrelu', alpha=None
     gain = float(spec.def_gain if gain is None else gain)
     clamp = float(-1 if clamp is None else clamp)
     fusable = 'x' not in spec.ref and not spec.has_2nd_grad
-    if impl == 'cuda' and x.device.type == 'cuda' and x.dtype != torch.float64 and fusable and x.is_contiguous():
+    if impl == 'cuda' and x.device.type == 'cuda' and x.dtype != torch.float64 and fusable and (x.is_contiguous() or _is_nhwc(x)):
         return _epilogue_hip(act, alpha, gain, clamp).apply(x, dcoefs, noise, noise_strength, b)
     if noise is not None and noise_strength is not None:
         noise = noise * noise_strength
@@ -167,12 +184,16 @@ class _ChannelScale(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, s):
         n, c, h, w = x.shape
-        x = x.contiguous()
+        nhwc = _is_nhwc(x)
+        if not nhwc:
+            x = x.contiguous()
         s32 = s.detach().to(x.dtype).to(torch.float32).contiguous()      # styles.to(x.dtype), as the reference
         y = torch.empty_like(x)
+        ctx.nhwc = nhwc
         if x.numel():
             with torch.cuda.device(x.device):
-                native.check(native.lib().mg_fma_bias_act(native.ptr(x), native.ptr(s32), native.ptr(None), native.ptr(None),
+                fwd = native.lib().mg_fma_bias_act_nhwc if nhwc else native.lib().mg_fma_bias_act
+                native.check(fwd(native.ptr(x), native.ptr(s32), native.ptr(None), native.ptr(None),
                                                           native.ptr(y), native.dtype_code(x.dtype), 1, 0.0, 1.0, -1.0, 1.0, native.ptr(None), 0,
                                                           n, c, h * w, native.stream_ptr(x.device)))
         ctx.save_for_backward(x, s)
@@ -186,14 +207,15 @@ class _ChannelScale(torch.autograd.Function):
             dx = dy * s.to(dy.dtype).reshape(n, c, 1, 1) if ctx.needs_input_grad[0] else None
             ds = (dy * x).sum(dim=[2, 3]).to(s.dtype) if ctx.needs_input_grad[1] else None
             return dx, ds
-        dy = dy.contiguous()
+        dy = dy.contiguous(memory_format=torch.channels_last) if ctx.nhwc else dy.contiguous()
         dx = torch.empty_like(x)
         want_ds = ctx.needs_input_grad[1]
         gd = torch.zeros([n * c], dtype=torch.float32, device=x.device) if want_ds else None
         s32 = s.to(x.dtype).to(torch.float32).contiguous()
         if x.numel():
             with torch.cuda.device(x.device):
-                native.check(native.lib().mg_bwd_fused(native.ptr(dy), native.ptr(None), native.ptr(x if want_ds else None),
+                bwd = native.lib().mg_bwd_fused_nhwc if ctx.nhwc else native.lib().mg_bwd_fused
+                native.check(bwd(native.ptr(dy), native.ptr(None), native.ptr(x if want_ds else None),
                                                        native.ptr(s32), native.ptr(None), native.ptr(dx), native.ptr(gd),
                                                        native.ptr(None), native.ptr(None), native.dtype_code(x.dtype), 1, 0.0, 1.0,
                                                        -1.0, 0, n, c, h * w, native.stream_ptr(x.device)))
@@ -203,6 +225,6 @@ class _ChannelScale(torch.autograd.Function):
 def channel_scale(x, s, impl='cuda'):
     """x [N,C,H,W] * s [N,C] broadcast over H,W -- the style modulation in front of a shared-weight convolution
     (reference training/networks.py:70: ``x * styles.to(x.dtype).reshape(batch_size, -1, 1, 1)``)."""
-    if impl == 'cuda' and x.device.type == 'cuda' and x.dtype != torch.float64 and x.ndim == 4 and x.is_contiguous():
+    if impl == 'cuda' and x.device.type == 'cuda' and x.dtype != torch.float64 and x.ndim == 4 and (x.is_contiguous() or _is_nhwc(x)):
         return _ChannelScale.apply(x, s)
     return x * s.to(x.dtype).reshape(x.shape[0], -1, 1, 1)

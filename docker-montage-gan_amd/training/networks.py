@@ -259,7 +259,7 @@ class SynthesisLayer(torch.nn.Module):
             y = modconv_epilogue.channel_scale(x, st)
             y = conv2d_resample.conv2d_resample(x=y, w=weight.to(x.dtype), f=self.resample_filter, up=self.up,
                                                 padding=self.padding, flip_weight=flip_weight)
-            if y.is_contiguous():
+            if y.is_contiguous() or modconv_epilogue._is_nhwc(y):
                 return modconv_epilogue.modconv_epilogue(y, dcoefs, noise_raw, self.bias, act=self.activation, gain=act_gain,
                                                          clamp=act_clamp, noise_strength=self.noise_strength if noise_raw is not None else None)
             noise = noise_raw * self.noise_strength if noise_raw is not None else None

@@ -64,6 +64,7 @@ enum {
     MG_K_FILTERED_LRELU = 9,
     MG_K_BWD_FUSED = 10,
     MG_K_UPFIRDN2D_STREAM = 11,
+    MG_K_UPFIRDN2D_NHWC = 12,
     MG_K_COUNT = 16
 };
 
@@ -149,6 +150,19 @@ int mg_fma_bias_act_bwd(const void* dy, const void* yref, const float* d,
 int mg_bwd_fused(const void* dy, const void* yref, const void* x, const float* d, const float* noise,
                  void* dx, float* gd, float* gb, float* gs, int dtype, int act, float alpha, float gain,
                  float clamp, int64_t noise_stride_n, int32_t n, int32_t c, int32_t hw, void* stream);
+
+/* ---- channels-last (NHWC) epilogue and fused backward ----------------------------
+ * Same arithmetic as mg_fma_bias_act / mg_bwd_fused on a tensor whose MEMORY is [N, HW, C] (torch.channels_last,
+ * which the reference's bf16/fp16 blocks may run in: training/networks.py `fp16_channels_last`, bias_act.py:157
+ * keeps the layout).  c must be a multiple of the 16-byte vector (8 for 16-bit types, 4 for float32); for the
+ * backward additionally (c / vector) must divide 256.  `gb_partial` is [N*C]: per-sample partial bias sums
+ * (the caller adds them over N); gd is [N*C], gs is [1]; all float32, zero-filled by the caller.              */
+int mg_fma_bias_act_nhwc(const void* x, const float* d, const float* noise, const void* b, void* y, int dtype,
+                         int act, float alpha, float gain, float clamp, float noise_gain, const float* noise_gain_dev,
+                         int64_t noise_stride_n, int32_t n, int32_t c, int32_t hw, void* stream);
+int mg_bwd_fused_nhwc(const void* dy, const void* yref, const void* x, const float* d, const float* noise,
+                      void* dx, float* gd, float* gb_partial, float* gs, int dtype, int act, float alpha, float gain,
+                      float clamp, int64_t noise_stride_n, int32_t n, int32_t c, int32_t hw, void* stream);
 
 /* ---- alpha composite -------------------------------------------------------
  * x: [B, L, 4, H, W] contiguous (RGB + alpha, values nominally in [0,1]);

@@ -152,6 +152,101 @@ def test_upfirdn2d_stream_kernel_bit_exact_and_edges(native, oracle, dtype):
     close_lowp(got.float().cpu().numpy(), want, dtype, 'stream random')
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+def test_upfirdn2d_nhwc_kernel_bit_exact_and_edges(native, oracle, dtype):
+    """The channels-last kernel (dense NHWC, <= 4x4 taps, up/down in {1,2}): every polyphase instantiation (both
+    tile phases per axis for up=2), odd sizes, chunk boundaries (> 32 output rows), negative pads, flipped taps --
+    exact on small integers, so any index-path slip is a bit difference."""
+    rng = np.random.RandomState(33)
+    plugin = custom_ops().get_plugin('upfirdn2d_plugin')
+    vec = 16 // torch.empty([], dtype=dtype).element_size()
+    lo, hi = (-8, 9) if dtype != torch.bfloat16 else (-1, 2)
+    taps = {'k4': [1, 3, 3, 1], 'k3': [1, 2, 1]} if dtype != torch.bfloat16 else {'k2': [1, 1], 'k4b': [1, 1, 1, 1]}
+    cfgs = [(1, 1, [1, 1, 1, 1]), (1, 1, [2, 2, 2, 2]), (1, 1, [3, 0, -1, 2]), (2, 1, [2, 1, 2, 1]), (2, 1, [1, 2, 2, 1]),
+            (2, 1, [2, 1, 1, 2]), (2, 1, [3, 2, 1, 0]), (1, 2, [1, 1, 1, 1]), (1, 2, [0, 2, 2, 0]), (1, 2, [-1, 3, 2, 1])]
+    before = native.launch_count(native.K_UPFIRDN2D_NHWC)
+    ncalls = 0
+    for shape in ([2, vec, 37, 45], [1, 2 * vec, 70, 33], [2, 3 * vec, 8, 8], [1, vec, 131, 5]):
+        for up, down, pad in cfgs:
+            for fk, tp in taps.items():
+                v = np.asarray(tp, dtype=np.float32)
+                f = np.outer(v, v)
+                if (shape[2] * up + pad[2] + pad[3] - f.shape[0]) // down + 1 < 1 or (shape[3] * up + pad[0] + pad[1] - f.shape[1]) // down + 1 < 1:
+                    continue
+                x = rng.randint(lo, hi, size=shape).astype(np.float32)
+                for flip in (False, True):
+                    want = oracle.upfirdn2d(x, f, (up, up), (down, down), tuple(pad), flip, 1.0)
+                    xg = T(x).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+                    got = plugin.upfirdn2d(xg, T(f).to(DEV), up, up, down, down, pad[0], pad[1], pad[2], pad[3], flip, 1.0)
+                    ncalls += 1
+                    assert got.dtype == dtype and tuple(got.shape) == want.shape
+                    assert got.is_contiguous(memory_format=torch.channels_last)
+                    assert np.array_equal(got.float().cpu().numpy(), want), (shape, up, down, pad, fk, flip, dtype)
+    assert native.launch_count(native.K_UPFIRDN2D_NHWC) - before == ncalls, 'the channels-last kernel did not take these calls'
+    # random data, asymmetric filter, gain, network-like shape
+    f = rng.randn(4, 3).astype(np.float32)
+    x = rng.randn(2, 4 * vec, 65, 65).astype(np.float32)
+    for up, down, pad, gain in [(1, 1, (1, 1, 1, 1), 4.0), (2, 1, (2, 1, 2, 1), 4.0), (1, 2, (1, 1, 1, 1), 1.0)]:
+        want = oracle.upfirdn2d(T(x).to(dtype).float().numpy(), f, (up, up), (down, down), pad, False, gain)
+        xg = T(x).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+        got = plugin.upfirdn2d(xg, T(f).to(DEV), up, up, down, down, pad[0], pad[1], pad[2], pad[3], False, gain)
+        close_lowp(got.float().cpu().numpy(), want, dtype, f'nhwc random up{up} down{down}')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+def test_channels_last_epilogue_and_backward_match_nchw(native, dtype):
+    """The NHWC epilogue / fused-backward / bias_act kernels against the NCHW kernels on the same values (the NCHW
+    ones are pinned to the oracle and the golden vectors above): forward and dx bit-identical (same arithmetic,
+    different addressing), the float32-accumulated reductions within rounding of the summation order."""
+    E, B = op('modconv_epilogue'), op('bias_act')
+    g = torch.Generator().manual_seed(8)
+    vec = 16 // torch.empty([], dtype=dtype).element_size()
+    for n, c, h, w in [(3, 4 * vec, 9, 7), (2, vec, 33, 32), (2, 16 * vec, 5, 5)]:
+        x0 = torch.randn([n, c, h, w], generator=g).to(dtype).to(DEV)
+        d0 = (torch.rand([n, c], generator=g) + 0.5).to(DEV)
+        b0 = torch.randn([c], generator=g).to(DEV)
+        nz = torch.randn([h, w], generator=g).to(DEV)
+        nzn = torch.randn([n, 1, h, w], generator=g).to(DEV)
+        gy = torch.randn([n, c, h, w], generator=g).to(dtype).to(DEV)
+        for noise in (nz, nzn, None):
+            res = []
+            for fmt in (torch.contiguous_format, torch.channels_last):
+                x = x0.clone().contiguous(memory_format=fmt).requires_grad_(True)
+                d, b = d0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+                st = torch.tensor(0.7, device=DEV, requires_grad=True)
+                k0 = native.launch_count(native.K_FMA_BIAS_ACT), native.launch_count(native.K_BWD_FUSED)
+                y = E.modconv_epilogue(x, d, noise, b, act='lrelu', clamp=1.5, noise_strength=st if noise is not None else None)
+                grads = torch.autograd.grad([y], [x, d, b] + ([st] if noise is not None else []), [gy.contiguous(memory_format=fmt)])
+                assert native.launch_count(native.K_FMA_BIAS_ACT) == k0[0] + 1 and native.launch_count(native.K_BWD_FUSED) == k0[1] + 1
+                if fmt == torch.channels_last:
+                    assert y.is_contiguous(memory_format=torch.channels_last) and grads[0].is_contiguous(memory_format=torch.channels_last)
+                res.append([y.detach()] + [t.detach() for t in grads])
+            assert torch.equal(res[0][0], res[1][0]), 'epilogue forward'
+            assert torch.equal(res[0][1], res[1][1]), 'epilogue dx'
+            for a, bb, what in zip(res[0][2:], res[1][2:], ['gd', 'gb', 'gs']):
+                close_lowp(bb.float().cpu().numpy(), a.float().cpu().numpy(), torch.float32 if dtype == torch.float32 else dtype, what)
+        # channel_scale
+        res = []
+        for fmt in (torch.contiguous_format, torch.channels_last):
+            x = x0.clone().contiguous(memory_format=fmt).requires_grad_(True)
+            d = d0.clone().requires_grad_(True)
+            y = E.channel_scale(x, d)
+            gx, gd = torch.autograd.grad([y], [x, d], [gy.contiguous(memory_format=fmt)])
+            res.append((y.detach(), gx, gd))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), 'channel_scale'
+        close_lowp(res[1][2].float().cpu().numpy(), res[0][2].float().cpu().numpy(), torch.float32 if dtype == torch.float32 else dtype, 'channel_scale gd')
+        # bias_act with its fused bias gradient
+        res = []
+        for fmt in (torch.contiguous_format, torch.channels_last):
+            x = x0.clone().contiguous(memory_format=fmt).requires_grad_(True)
+            b = b0.to(dtype).clone().requires_grad_(True)
+            y = B.bias_act(x, b, act='lrelu', clamp=1.5)
+            gx, gb = torch.autograd.grad([y], [x, b], [gy.contiguous(memory_format=fmt)])
+            res.append((y.detach(), gx, gb))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), 'bias_act nhwc'
+        close_lowp(res[1][2].float().cpu().numpy(), res[0][2].float().cpu().numpy(), dtype, 'bias_act db')
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16, torch.float64])
 def test_upfirdn2d_dtypes_vs_oracle(native, oracle, dtype):
     rng = np.random.RandomState(11)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch ONE native kernel configuration a few times (for rocprofv3 --pmc runs).
-usage: kernel_loop.py <upfirdn2d|bias_act|epilogue> <dtype> [iters]"""
+usage: kernel_loop.py <upfirdn2d|up2|down2|bias_act|calib4|epilogue|bwd_fused> <dtype> [iters]"""
 import importlib
 import os
 import sys
@@ -32,14 +32,30 @@ elif which == 'calib4':
     base = torch.randn([n * c * r * r + 1], device=dev)
     x = base[1:].reshape(n, c, r, r)
     fn = lambda: B.bias_act(x, None, act='lrelu')
+elif which == 'up2':
+    x = torch.randn([n, c, r // 2, r // 2], device=dev).to(dt)
+    fn = lambda: U.upfirdn2d(x, f, up=2, padding=[2, 1, 2, 1], gain=4)
+elif which == 'down2':
+    x = torch.randn([n, c, r, r], device=dev).to(dt)
+    fn = lambda: U.upfirdn2d(x, f, down=2, padding=[1, 1, 1, 1])
+elif which == 'bwd_fused':
+    x = torch.randn([n, c, r, r], device=dev).to(dt).requires_grad_(True)
+    d = (torch.rand([n, c], device=dev) + 0.5).requires_grad_(True)
+    nz = torch.randn([r, r], device=dev)
+    b = torch.randn([c], device=dev).requires_grad_(True)
+    st = torch.ones([], device=dev, requires_grad=True)
+    ye = E.modconv_epilogue(x, d, nz, b, act='lrelu', clamp=256, noise_strength=st)
+    gy = torch.randn_like(ye)
+    torch.set_grad_enabled(True)
+    fn = lambda: torch.autograd.grad([ye], [x, d, b, st], [gy], retain_graph=True)[0]
 else:
     x = torch.randn([n, c, r, r], device=dev).to(dt)
     d = torch.rand([n, c], device=dev) + 0.5
     nz = torch.randn([r, r], device=dev)
     b = torch.randn([c], device=dev)
     fn = lambda: E.modconv_epilogue(x, d, nz, b, act='lrelu', clamp=256)
-with torch.no_grad():
+with (torch.enable_grad() if which == 'bwd_fused' else torch.no_grad()):
     for _ in range(iters):
         fn()
 torch.cuda.synchronize()
-print('algorithmic bytes per launch:', (x.numel() + fn().numel()) * x.element_size())
+print('algorithmic bytes per launch:', (4 * x.numel() if which == 'bwd_fused' else x.numel() + fn().numel()) * x.element_size())

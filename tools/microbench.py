@@ -68,6 +68,19 @@ def main():
         nz = torch.randn([r, r], device=dev)
         with torch.no_grad():
             rec(f'modconv_epilogue fwd [{n},{c},{r},{r}]', timeit(lambda: E.modconv_epilogue(x, d, nz, b, act='lrelu', clamp=256)), 2 * x.numel() * es)
+        xr = x.clone().requires_grad_(True)
+        dr = d.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True)
+        st = torch.ones([], device=dev, requires_grad=True)
+        ye = E.modconv_epilogue(xr, dr, nz, br, act='lrelu', clamp=256, noise_strength=st)
+        gy = torch.randn_like(ye)
+        rec(f'modconv_epilogue bwd (dx,gd,gb,gs) [{n},{c},{r},{r}]',
+            timeit(lambda: torch.autograd.grad([ye], [xr, dr, br, st], [gy], retain_graph=True)), 4 * x.numel() * es)
+        ys = E.channel_scale(xr, dr)
+        rec(f'channel_scale fwd [{n},{c},{r},{r}]', timeit(lambda: E.channel_scale(x, d)), 2 * x.numel() * es)
+        rec(f'channel_scale bwd (dx,gd) [{n},{c},{r},{r}]',
+            timeit(lambda: torch.autograd.grad([ys], [xr, dr], [gy], retain_graph=True)), 3 * x.numel() * es)
+        del xr, ye, ys, gy
         xp = torch.randn([n, c, r + 1, r + 1], device=dev).to(dt)
         rec(f'upfirdn2d 4x4 1:1 [{n},{c},{r + 1}]->[{r}]', timeit(lambda: U.upfirdn2d(xp, f, padding=[1, 1, 1, 1], gain=4)),
             (xp.numel() + x.numel()) * es)
