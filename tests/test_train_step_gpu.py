@@ -105,6 +105,57 @@ def test_mixed_precision_step_is_finite_and_close(dtype):
     assert all(torch.isfinite(p.grad).all() for p in S16.parameters() if p.grad is not None)
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('one_by_one', ['conv', 'matmul'])
+def test_channels_last_blocks_match_nchw_blocks(dtype, one_by_one):
+    """fp16_channels_last (reference training/networks.py:298/427) only changes the memory layout of the
+    reduced-precision blocks: generator images, discriminator logits and parameter gradients must agree with the
+    NCHW run up to the convolution library's summation order, and the NHWC native kernels must be the ones running."""
+    native = load_pkg().native
+    NW, CR = mod('training.networks'), mod('torch_utils.ops.conv2d_resample')
+    CR.nhwc_1x1_workaround = (one_by_one == 'matmul')
+    try:
+        torch.manual_seed(1)
+        kw = dict(w_dim=64, img_resolution=64, img_channels=4, channel_base=2048, channel_max=64, conv_clamp=256, num_fp16_res=3, fp16_dtype=dtype)
+        Sa = NW.SynthesisNetwork(**kw).to(DEV).train()
+        Sb = NW.SynthesisNetwork(fp16_channels_last=True, **kw).to(DEV).train()
+        Sb.load_state_dict(Sa.state_dict())
+        dkw = dict(c_dim=0, img_resolution=64, img_channels=4, channel_base=2048, channel_max=64, conv_clamp=256, num_fp16_res=3)
+        Da = NW.Discriminator(block_kwargs=dict(fp16_dtype=dtype), **dkw).to(DEV).train()
+        Db = NW.Discriminator(block_kwargs=dict(fp16_dtype=dtype, fp16_channels_last=True), **dkw).to(DEV).train()
+        Db.load_state_dict(Da.state_dict())
+        # float32 twins give the yardstick: the NHWC run may not sit further from them than the NCHW run does
+        S32 = NW.SynthesisNetwork(**dict(kw, num_fp16_res=0)).to(DEV).train()
+        S32.load_state_dict(Sa.state_dict())
+        D32 = NW.Discriminator(**dict(dkw, num_fp16_res=0)).to(DEV).train()
+        D32.load_state_dict(Da.state_dict())
+        ws = torch.randn([4, Sa.num_ws, 64], device=DEV)
+        before = native.launch_counts()
+        outs = []
+        for S, D in ((Sa, Da), (Sb, Db), (S32, D32)):
+            img = S(ws, noise_mode='const')
+            logits = D(img, None)
+            torch.nn.functional.softplus(-logits).mean().backward()
+            outs.append((img.detach(), logits.detach(), [p.grad for p in S.parameters()] + [p.grad for p in D.parameters()]))
+        after = native.launch_counts()
+        assert after['upfirdn2d_nhwc'] > before['upfirdn2d_nhwc'], 'the channels-last FIR kernel did not run'
+        tol = 0.02 if dtype == torch.float16 else 0.08
+        (ia, la, ga_all), (ib, lb, gb_all), (i32, l32, g32_all) = outs
+        assert torch.isfinite(ib).all() and torch.isfinite(lb).all()
+        assert float((ia - ib).abs().mean() / ia.abs().mean()) < tol
+        assert float((la - lb).abs().max() / la.abs().max().clamp_min(1e-3)) < 4 * tol
+
+        def rel(a, b):
+            return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12))
+        for ga, gb, g32 in zip(ga_all, gb_all, g32_all):
+            assert (ga is None) == (gb is None)
+            if ga is not None and ga.numel() > 1 and float(g32.abs().max()) > 0:
+                assert torch.isfinite(gb).all()
+                assert rel(gb, g32) <= 2 * rel(ga, g32) + tol, (rel(gb, g32), rel(ga, g32), tuple(ga.shape))
+    finally:
+        CR.nhwc_1x1_workaround = True
+
+
 def test_aio_iteration_runs_native_and_updates_weights():
     """One full (tiny) train_aio iteration on the GPU: every phase fires at batch_idx 0; the native kernels
     run; weights move; a second iteration skips the lazy-regularisation phases."""
@@ -126,6 +177,7 @@ def test_aio_iteration_runs_native_and_updates_weights():
               'translate_bwd_shift'):
         assert after[k] > before[k], k
     assert after['upfirdn2d_tiled'] + after['upfirdn2d_stream'] > before['upfirdn2d_tiled'] + before['upfirdn2d_stream']
+    assert after['upfirdn2d_nhwc'] == before['upfirdn2d_nhwc']       # NCHW configuration: the channels-last kernel stays idle
     assert t.run_iteration() == 8           # only the main phases at batch_idx 1
     torch.cuda.synchronize()
     w1 = [p.detach() for p in t.local_G_list[0].parameters()][:3]

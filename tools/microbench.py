@@ -14,16 +14,28 @@ sys.path.insert(0, ROOT)
 PKG = 'docker-montage-gan_amd'
 
 
+_native = None
+
+
 def timeit(fn, iters=20, warm=3):
+    """Average time of the NATIVE kernels one call launches (HIP event pairs around each launch, on the launch
+    stream) -- host gaps and aten helper kernels between them are not counted.  Falls back to wall-clock events
+    around the loop when the call launches no native kernel (copy_)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    _native.prof_reset(); _native.prof_enable(True)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
         fn()
     b.record()
     torch.cuda.synchronize()
+    _native.prof_enable(False)
+    rec = _native.prof_collect()
+    _native.prof_reset()
+    if rec:
+        return sum(v['ms'] for v in rec.values()) / iters
     return a.elapsed_time(b) / iters
 
 
@@ -32,8 +44,10 @@ def main():
     ap.add_argument('--dtype', default='float32')
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--out', default=None)
+    ap.add_argument('--layout', default='nchw', choices=['nchw', 'nhwc'])
     args = ap.parse_args()
-    importlib.import_module(PKG)
+    global _native
+    _native = importlib.import_module(PKG).native
     U = importlib.import_module(f'{PKG}.torch_utils.ops.upfirdn2d')
     B = importlib.import_module(f'{PKG}.torch_utils.ops.bias_act')
     A = importlib.import_module(f'{PKG}.torch_utils.ops.alpha_composite')
@@ -45,6 +59,7 @@ def main():
     n = args.batch
     f = U.setup_filter([1, 3, 3, 1]).to(dev)
     rows = []
+    fmt = torch.channels_last if args.layout == 'nhwc' else torch.contiguous_format
 
     def rec(name, ms, nbytes):
         rows.append(dict(kernel=name, ms=round(ms, 4), GBps=round(nbytes / ms / 1e6, 1)))
@@ -57,7 +72,7 @@ def main():
     del big, dst
 
     for r, c in [(256, 64), (128, 128), (64, 256), (32, 512)]:
-        x = torch.randn([n, c, r, r], device=dev).to(dt)
+        x = torch.randn([n, c, r, r], device=dev).to(dt).contiguous(memory_format=fmt)
         b = torch.randn([c], device=dev).to(dt)
         rec(f'bias_act lrelu fwd [{n},{c},{r},{r}]', timeit(lambda: B.bias_act(x, b, act='lrelu', clamp=256)), 2 * x.numel() * es)
         y = B.bias_act(x, b, act='lrelu', clamp=256)
@@ -73,7 +88,7 @@ def main():
         br = b.clone().requires_grad_(True)
         st = torch.ones([], device=dev, requires_grad=True)
         ye = E.modconv_epilogue(xr, dr, nz, br, act='lrelu', clamp=256, noise_strength=st)
-        gy = torch.randn_like(ye)
+        gy = torch.randn_like(ye)      # preserves the layout of ye
         rec(f'modconv_epilogue bwd (dx,gd,gb,gs) [{n},{c},{r},{r}]',
             timeit(lambda: torch.autograd.grad([ye], [xr, dr, br, st], [gy], retain_graph=True)), 4 * x.numel() * es)
         ys = E.channel_scale(xr, dr)
@@ -81,14 +96,14 @@ def main():
         rec(f'channel_scale bwd (dx,gd) [{n},{c},{r},{r}]',
             timeit(lambda: torch.autograd.grad([ys], [xr, dr], [gy], retain_graph=True)), 3 * x.numel() * es)
         del xr, ye, ys, gy
-        xp = torch.randn([n, c, r + 1, r + 1], device=dev).to(dt)
+        xp = torch.randn([n, c, r + 1, r + 1], device=dev).to(dt).contiguous(memory_format=fmt)
         rec(f'upfirdn2d 4x4 1:1 [{n},{c},{r + 1}]->[{r}]', timeit(lambda: U.upfirdn2d(xp, f, padding=[1, 1, 1, 1], gain=4)),
             (xp.numel() + x.numel()) * es)
         rec(f'upfirdn2d 4x4 1:1 [{n},{c},{r}]->[{r + 1}]', timeit(lambda: U.upfirdn2d(x, f, padding=[2, 2, 2, 2])),
             (xp.numel() + x.numel()) * es)
         rec(f'upfirdn2d 4x4 down2 [{n},{c},{r}]->[{r // 2}]', timeit(lambda: U.upfirdn2d(x, f, down=2, padding=[1, 1, 1, 1])),
             (x.numel() + x.numel() // 4) * es)
-        xh = torch.randn([n, c, r // 2, r // 2], device=dev).to(dt)
+        xh = torch.randn([n, c, r // 2, r // 2], device=dev).to(dt).contiguous(memory_format=fmt)
         rec(f'upfirdn2d 4x4 up2 [{n},{c},{r // 2}]->[{r}]', timeit(lambda: U.upfirdn2d(xh, f, up=2, padding=[2, 1, 2, 1], gain=4)),
             (x.numel() + xh.numel()) * es)
         del x, xp, xh, y
