@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256) bwd_fused_kernel(BrArgs<T> p)
     if (threadIdx.x == 0) {
         if (p.gd) atomicAdd(p.gd + plane, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
         if (p.gb) atomicAdd(p.gb + ch, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
-        if (p.gs) atomicAdd(p.gs, red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+        if (p.gs) atomicAdd(p.gs + (blockIdx.x % MG_GS_SLOTS), red[2][0] + red[2][1] + red[2][2] + red[2][3]);   // spread: one address would serialise
     }
 }
 
@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(256) bwd_fused_nhwc_kernel(BnArgs<T> p)
         __shared__ float red_s[4];
         if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = s_gs;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(p.gs, red_s[0] + red_s[1] + red_s[2] + red_s[3]);
+        if (threadIdx.x == 0) atomicAdd(p.gs + (blockIdx.x % MG_GS_SLOTS), red_s[0] + red_s[1] + red_s[2] + red_s[3]);
     }
 }
 

@@ -19,9 +19,12 @@ K_UPFIRDN2D_GENERIC, K_UPFIRDN2D_TILED, K_BIAS_ACT, K_FMA_BIAS_ACT = 0, 1, 2, 3
 K_ALPHA_COMPOSITE_FWD, K_ALPHA_COMPOSITE_BWD, K_TRANSLATE_FWD, K_TRANSLATE_BWD_INPUT = 4, 5, 6, 7
 K_TRANSLATE_BWD_SHIFT, K_FILTERED_LRELU, K_BWD_FUSED, K_UPFIRDN2D_STREAM = 8, 9, 10, 11
 K_UPFIRDN2D_NHWC = 12
+K_AFFINE_WARP_FWD, K_AFFINE_WARP_BWD, K_CHANNEL_MIX = 13, 14, 15
+GS_SLOTS = 64       # MG_GS_SLOTS
 KERNEL_NAMES = {0: 'upfirdn2d_generic', 1: 'upfirdn2d_tiled', 2: 'bias_act', 3: 'fma_bias_act', 4: 'alpha_composite_fwd',
                 5: 'alpha_composite_bwd', 6: 'translate_fwd', 7: 'translate_bwd_input', 8: 'translate_bwd_shift',
-                9: 'filtered_lrelu', 10: 'bwd_fused', 11: 'upfirdn2d_stream', 12: 'upfirdn2d_nhwc'}
+                9: 'filtered_lrelu', 10: 'bwd_fused', 11: 'upfirdn2d_stream', 12: 'upfirdn2d_nhwc',
+                13: 'affine_warp_fwd', 14: 'affine_warp_bwd', 15: 'channel_mix'}
 
 _lib = None
 _lock = threading.Lock()
@@ -56,6 +59,9 @@ def _declare(L):
                                       c_float, c_i32, c_i32, c_i32, c_void_p]
     L.mg_bwd_fused.argtypes = [c_void_p] * 9 + [c_int, c_int, c_float, c_float, c_float, c_i64, c_i32, c_i32, c_i32, c_void_p]
     L.mg_fma_bias_act_nhwc.argtypes = L.mg_fma_bias_act.argtypes
+    L.mg_affine_warp_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]
+    L.mg_affine_warp_bwd.argtypes = L.mg_affine_warp_fwd.argtypes
+    L.mg_channel_mix.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i32, c_i32, c_i64, c_void_p]
     L.mg_bwd_fused_nhwc.argtypes = L.mg_bwd_fused.argtypes
     L.mg_alpha_composite_fwd.argtypes = [c_void_p, c_void_p, c_int, c_i32, c_i32, c_i32, c_i32, c_void_p]
     L.mg_alpha_composite_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_i32, c_i32, c_i32, c_i32, c_int, c_void_p]
@@ -68,7 +74,7 @@ def _declare(L):
     for name in ('mg_upfirdn2d', 'mg_upfirdn2d_index_table', 'mg_bias_act', 'mg_fma_bias_act', 'mg_fma_bias_act_bwd',
                  'mg_alpha_composite_fwd', 'mg_alpha_composite_bwd', 'mg_translate_sample_fwd',
                  'mg_translate_sample_bwd_input', 'mg_translate_sample_bwd_shift', 'mg_filtered_lrelu', 'mg_bwd_fused',
-                 'mg_fma_bias_act_nhwc', 'mg_bwd_fused_nhwc',
+                 'mg_fma_bias_act_nhwc', 'mg_bwd_fused_nhwc', 'mg_affine_warp_fwd', 'mg_affine_warp_bwd', 'mg_channel_mix',
                  'mg_prof_enable', 'mg_prof_collect', 'mg_prof_reset'):
         getattr(L, name).restype = c_int
 

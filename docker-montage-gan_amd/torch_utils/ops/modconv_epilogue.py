@@ -133,8 +133,8 @@ def _epilogue_hip(act, alpha, gain, clamp):
             want_gn = has_nz and need[2]
             dx = torch.empty_like(x)
             nb = n * c if nhwc else c       # the NHWC kernel leaves per-sample partial bias sums
-            acc = torch.zeros([n * c + nb + 4], dtype=torch.float32, device=x.device)
-            gd_a, gb_a, gs_a = acc[:n * c], acc[n * c:n * c + nb], acc[n * c + nb:n * c + nb + 1]
+            acc = torch.zeros([n * c + nb + native.GS_SLOTS], dtype=torch.float32, device=x.device)
+            gd_a, gb_a, gs_a = acc[:n * c], acc[n * c:n * c + nb], acc[n * c + nb:]     # gs: GS_SLOTS partial sums
             stride = ctx.noise_meta[2] if has_nz else 0
             d32 = dcoefs.to(x.dtype).to(torch.float32).contiguous() if has_d else None
             if x.numel():
@@ -147,7 +147,7 @@ def _epilogue_hip(act, alpha, gain, clamp):
                         native.dtype_code(x.dtype), idx, alpha, gain, clamp, stride, n, c, h * w, native.stream_ptr(x.device)))
             gd = gd_a.reshape(n, c).to(dcoefs.dtype) if want_gd else None
             gb = (gb_a.reshape(n, c).sum(0) if nhwc else gb_a).to(ctx.b_dtype) if want_gb else None
-            gs = gs_a.reshape([]).to(ctx.s_dtype) if want_gs else None
+            gs = gs_a.sum().to(ctx.s_dtype) if want_gs else None
             gn = None
             if want_gn:         # a caller-scaled noise tensor that wants its own gradient: not the hot path
                 dt, shp, stride = ctx.noise_meta

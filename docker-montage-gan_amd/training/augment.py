@@ -6,8 +6,9 @@ RGBA branch of the colour stage :403-406), so that a seeded CPU run reproduces i
 ``debug_percentile`` gives the same deterministic images.
 
 It is the main consumer of the separable resampler: the geometric stage is
-``pad(reflect) -> upfirdn2d.upsample2d(sym6, x2) -> grid_sample_gradfix.grid_sample -> upfirdn2d.downsample2d(sym6, /2)``
-i.e. four launches of csrc/upfirdn2d.hip (two separable passes each) around aten's sampler.
+``pad(reflect) -> upfirdn2d.upsample2d(sym6, x2) -> affine_warp (= affine_grid + grid_sample) -> upfirdn2d.downsample2d(sym6, /2)``
+i.e. four launches of csrc/upfirdn2d.hip (two separable passes each) around the native resampler of csrc/augment.hip;
+the colour matrix is one native pass (channel_mix) instead of a 3-row batched GEMM.
 Host-sync note: upstream reads the data-dependent reflect-padding margin back as python ints (:313), one
 device->host synchronisation per discriminator call -- on a GPU-bound step that serialises host and device time.
 Two module switches remove that wait (both off by default = upstream behaviour):
@@ -24,7 +25,9 @@ import torch
 
 from ..torch_utils import misc
 from ..torch_utils.ops import conv2d_gradfix
-from ..torch_utils.ops import grid_sample_gradfix
+from ..torch_utils.ops import affine_warp
+from ..torch_utils.ops import channel_mix
+from ..torch_utils.ops import grid_sample_gradfix  # noqa: F401  (reference import; affine_warp falls back to it)
 from ..torch_utils.ops import upfirdn2d
 
 fixed_margin = False          # True: never read the padding margin back to the host (see module docstring)
@@ -252,8 +255,7 @@ class AugmentPipe(torch.nn.Module):
             # sample on the output lattice
             shape = [n, ch, (height + hz_pad * 2) * 2, (width + hz_pad * 2) * 2]
             G_inv = scale2d(2 / images.shape[3], 2 / images.shape[2], device=dev) @ G_inv @ scale2d_inv(2 / shape[3], 2 / shape[2], device=dev)
-            grid = torch.nn.functional.affine_grid(theta=G_inv[:, :2, :], size=shape, align_corners=False)
-            images = grid_sample_gradfix.grid_sample(images, grid)
+            images = affine_warp.affine_warp(images, G_inv[:, :2, :], shape[2], shape[3])     # affine_grid + grid_sample, one pass
             # back down, cropping the filter margin
             images = upfirdn2d.downsample2d(x=images, f=self.Hz_geom, down=2, padding=-hz_pad * 2, flip_filter=True)
 
@@ -295,9 +297,11 @@ class AugmentPipe(torch.nn.Module):
         if C is not I_4:
             flat = images.reshape([n, ch, height * width])
             if ch == 4:         # RGBA: colour matrix on RGB, alpha untouched (reference :403-406)
-                flat = torch.cat([C[:, :3, :3] @ flat[:, :3, :] + C[:, :3, 3:], flat[:, 3:, :]], dim=1)
+                A4 = I_4.repeat([n, 1, 1])
+                A4[:, :3, :3] = C[:, :3, :3]
+                flat = channel_mix.channel_mix(flat, A4, torch.nn.functional.pad(C[:, :3, 3], [0, 1]))
             elif ch == 3:
-                flat = C[:, :3, :3] @ flat + C[:, :3, 3:]
+                flat = channel_mix.channel_mix(flat, C[:, :3, :3], C[:, :3, 3])
             elif ch == 1:
                 Cm = C[:, :3, :].mean(dim=1, keepdims=True)
                 flat = flat * Cm[:, :, :3].sum(dim=2, keepdims=True) + Cm[:, :, 3:]

@@ -38,6 +38,7 @@ extern "C" {
 #endif
 
 #define MG_ABI_VERSION 1
+#define MG_GS_SLOTS 64          /* length of the `gs` accumulator of mg_bwd_fused / mg_bwd_fused_nhwc */
 
 /* element types of activation tensors */
 enum { MG_F32 = 0, MG_F16 = 1, MG_BF16 = 2, MG_F64 = 3 };
@@ -65,6 +66,9 @@ enum {
     MG_K_BWD_FUSED = 10,
     MG_K_UPFIRDN2D_STREAM = 11,
     MG_K_UPFIRDN2D_NHWC = 12,
+    MG_K_AFFINE_WARP_FWD = 13,
+    MG_K_AFFINE_WARP_BWD = 14,
+    MG_K_CHANNEL_MIX = 15,
     MG_K_COUNT = 16
 };
 
@@ -143,7 +147,8 @@ int mg_fma_bias_act_bwd(const void* dy, const void* yref, const float* d,
  *   dx   = d ? dpre * d[n,c] : dpre                      (written)
  *   gd[n,c] += sum_hw dpre * x        (x, gd non NULL)   -- d(dcoefs) of the epilogue, d(styles) of the modulation
  *   gb[c]   += sum_{n,hw} dpre        (gb non NULL)      -- d(bias)
- *   gs[0]   += sum dpre * noise[n,hw] (noise, gs non NULL) -- d(noise_strength)
+ *   gs[k]   += partial sums of dpre * noise[n,hw] (noise, gs non NULL) -- d(noise_strength) = sum of the
+ *              MG_GS_SLOTS entries of gs (spread over slots so that the atomics do not pile on one address)
  * gd/gb/gs are float32 accumulators the caller zero-fills (float atomics, one per workgroup and sum).
  * Covers: bias_act backward + bias gradient (bias_act.py:186-196), the fma/bias_act epilogue backward
  * (fma.py:31-47) and the backward of x * styles[N,C,1,1] (training/networks.py:70).                      */
@@ -156,13 +161,29 @@ int mg_bwd_fused(const void* dy, const void* yref, const void* x, const float* d
  * which the reference's bf16/fp16 blocks may run in: training/networks.py `fp16_channels_last`, bias_act.py:157
  * keeps the layout).  c must be a multiple of the 16-byte vector (8 for 16-bit types, 4 for float32); for the
  * backward additionally (c / vector) must divide 256.  `gb_partial` is [N*C]: per-sample partial bias sums
- * (the caller adds them over N); gd is [N*C], gs is [1]; all float32, zero-filled by the caller.              */
+ * (the caller adds them over N); gd is [N*C], gs is [MG_GS_SLOTS]; all float32, zero-filled by the caller.              */
 int mg_fma_bias_act_nhwc(const void* x, const float* d, const float* noise, const void* b, void* y, int dtype,
                          int act, float alpha, float gain, float clamp, float noise_gain, const float* noise_gain_dev,
                          int64_t noise_stride_n, int32_t n, int32_t c, int32_t hw, void* stream);
 int mg_bwd_fused_nhwc(const void* dy, const void* yref, const void* x, const float* d, const float* noise,
                       void* dx, float* gd, float* gb_partial, float* gs, int dtype, int act, float alpha, float gain,
                       float clamp, int64_t noise_stride_n, int32_t n, int32_t c, int32_t hw, void* stream);
+
+/* ---- ADA: affine resampling and colour matrix ------------------------------------
+ * mg_affine_warp_fwd:  y = grid_sample(x, affine_grid(theta, [N,C,out_h,out_w], align_corners=False),
+ *                          mode='bilinear', padding_mode='zeros', align_corners=False)
+ *   (reference training/augment.py:376-377 -> torch_utils/ops/grid_sample_gradfix.py:32-41); the grid is never
+ *   materialised.  x [N,C,in_h,in_w], y [N,C,out_h,out_w] contiguous, theta [N,2,3] float32, C <= 4.
+ * mg_affine_warp_bwd:  dx = adjoint of the above applied to dy (grid_sample_gradfix.py:62-70 without the unused
+ *   grid gradient), evaluated as a gather per input pixel -- deterministic, no atomics.
+ * mg_channel_mix:      y[n,i,p] = sum_j A[n,i,j] * x[n,j,p] + t[n,i]   (t may be NULL), C <= 4, x/y [N,C,hw]:
+ *   the colour transform of training/augment.py:398-411.                                                        */
+int mg_affine_warp_fwd(const void* x, const float* theta, void* y, int dtype, int32_t n, int32_t c,
+                       int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w, void* stream);
+int mg_affine_warp_bwd(const void* dy, const float* theta, void* dx, int dtype, int32_t n, int32_t c,
+                       int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w, void* stream);
+int mg_channel_mix(const void* x, const float* A, const float* t, void* y, int dtype, int32_t n, int32_t c,
+                   int64_t hw, void* stream);
 
 /* ---- alpha composite -------------------------------------------------------
  * x: [B, L, 4, H, W] contiguous (RGB + alpha, values nominally in [0,1]);

@@ -193,3 +193,42 @@ def translate_sample_bwd(x, dy, t, shift=0.0):
     getattr(lib(), 'orc_translate_sample_bwd' + _sfx(dt_))(_p(x), _p(dy), _p(t), _p(dx), _p(gt), c_int(m), c_int(c),
                                                            c_int(h), c_int(w), c_float(shift))
     return dx, gt
+
+
+def affine_warp(x, theta, out_h, out_w):
+    """grid_sample(x, affine_grid(theta, [N,C,out_h,out_w])), bilinear / zeros / align_corners=False
+    (training/augment.py:376-377).  x [N,C,H,W]; theta float32 [N,2,3]."""
+    dt = x.dtype
+    x = _dense(x, dt)
+    theta = _dense(theta, np.float32)
+    n, c, h, w = x.shape
+    y = np.empty([n, c, out_h, out_w], dtype=dt)
+    getattr(lib(), 'orc_affine_warp_fwd' + _sfx(dt))(_p(x), _p(theta), _p(y), c_int(n), c_int(c), c_int(h), c_int(w),
+                                                     c_int(out_h), c_int(out_w))
+    return y
+
+
+def affine_warp_bwd(dy, theta, in_h, in_w):
+    """gradient of affine_warp w.r.t. x for upstream gradient dy [N,C,out_h,out_w]."""
+    dt = dy.dtype
+    dy = _dense(dy, dt)
+    theta = _dense(theta, np.float32)
+    n, c, oh, ow = dy.shape
+    dx = np.empty([n, c, in_h, in_w], dtype=dt)
+    getattr(lib(), 'orc_affine_warp_bwd' + _sfx(dt))(_p(dy), _p(theta), _p(dx), c_int(n), c_int(c), c_int(in_h), c_int(in_w),
+                                                     c_int(oh), c_int(ow))
+    return dx
+
+
+def channel_mix(x, A, t=None):
+    """y[n,i,...] = sum_j A[n,i,j] x[n,j,...] + t[n,i]  (training/augment.py:403-406)."""
+    dt = x.dtype
+    x = _dense(x, dt)
+    A = _dense(A, np.float32)
+    t = _dense(t, np.float32) if t is not None else None
+    n, c = x.shape[:2]
+    hw = int(np.prod(x.shape[2:]))
+    y = np.empty_like(x)
+    getattr(lib(), 'orc_channel_mix' + _sfx(dt))(_p(x), _p(A), _p(t) if t is not None else None, _p(y), c_int(n), c_int(c),
+                                                 ctypes.c_long(hw))
+    return y

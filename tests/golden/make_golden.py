@@ -446,9 +446,50 @@ def gen_augment():
     save('augment', arrays, dict(cases=cases))
 
 
+def gen_warp():
+    """ADA's resampling step and colour matrix through the reference's own calls:
+    F.affine_grid + torch_utils.ops.grid_sample_gradfix.grid_sample (training/augment.py:376-377) and
+    `C[:, :3, :3] @ images + C[:, :3, 3:]` (training/augment.py:403-406), with first-order gradients."""
+    from torch_utils.ops import grid_sample_gradfix
+    g = torch.Generator().manual_seed(77)
+    arrays, cases = {}, []
+
+    def rot(deg, sx=1.0, sy=1.0, tx=0.0, ty=0.0):
+        a = np.deg2rad(deg)
+        return [[sx * np.cos(a), -sy * np.sin(a), tx], [sx * np.sin(a), sy * np.cos(a), ty]]
+    specs = [
+        ([2, 4, 20, 24], (20, 24), [rot(0), rot(17, 1.2, 0.8, 0.1, -0.2)]),
+        ([3, 3, 17, 31], (26, 22), [rot(-40, 0.7, 0.7), rot(90), rot(5, 2.2, 1.9, 0.6, 0.4)]),
+        ([2, 1, 9, 9], (12, 7), [rot(180, 1, 1, 1.5, 0), rot(33, 0.3, 3.0)]),
+        ([1, 4, 32, 32], (44, 44), [[[1.0, 0.0, 2.0 / 32], [0.0, 1.0, -1.0 / 32]]]),       # integer-pixel shift: exact corners
+    ]
+    for i, (shape, (oh, ow), th) in enumerate(specs):
+        x = torch.randn(shape, generator=g, requires_grad=True)
+        theta = torch.tensor(np.asarray(th), dtype=torch.float32)
+        grid = torch.nn.functional.affine_grid(theta=theta, size=[shape[0], shape[1], oh, ow], align_corners=False)
+        y = grid_sample_gradfix.grid_sample(x, grid)
+        gy = torch.randn(y.shape, generator=g)
+        dx, = torch.autograd.grad([y], [x], [gy])
+        arrays.update({f'w{i}_x': x.detach(), f'w{i}_theta': theta, f'w{i}_y': y.detach(), f'w{i}_gy': gy, f'w{i}_dx': dx})
+        cases.append(dict(id=i, kind='warp', shape=shape, out=[oh, ow]))
+    for i, ch in enumerate([4, 3]):
+        n, hw = 3, 50
+        x = torch.randn([n, ch, hw], generator=g, requires_grad=True)
+        C = torch.eye(4).repeat(n, 1, 1) + 0.3 * torch.randn([n, 4, 4], generator=g)
+        if ch == 4:
+            y = torch.cat([C[:, :3, :3] @ x[:, :3, :] + C[:, :3, 3:], x[:, 3:, :]], dim=1)
+        else:
+            y = C[:, :3, :3] @ x + C[:, :3, 3:]
+        gy = torch.randn(y.shape, generator=g)
+        dx, = torch.autograd.grad([y], [x], [gy])
+        arrays.update({f'm{i}_x': x.detach(), f'm{i}_C': C, f'm{i}_y': y.detach(), f'm{i}_gy': gy, f'm{i}_dx': dx})
+        cases.append(dict(id=i, kind='mix', channels=ch))
+    save('warp', arrays, dict(cases=cases))
+
+
 if __name__ == '__main__':
     _import_reference()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv', 'montage', 'nets', 'augment']
+    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv', 'montage', 'nets', 'augment', 'warp']
     for w in which:
         globals()['gen_' + w]()

@@ -570,6 +570,92 @@ def test_translate_sample_full_size_properties(native):
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
 
 
+def test_affine_warp_golden_oracle_and_adjointness(native, oracle):
+    """ADA's resampling step as one native pass (csrc/augment.hip): the reference's golden outputs and input
+    gradients, the CPU oracle on rotations / anisotropic scales / far translations, the gather-form adjoint against
+    the scatter-form oracle, second-order use (backward of backward = forward), and -- at the bench shape -- the
+    size-independent adjointness property <W x, g> = <x, W^T g>."""
+    W = op('affine_warp')
+    cases, arr = load_golden('warp')
+    k0 = native.launch_count(native.K_AFFINE_WARP_FWD), native.launch_count(native.K_AFFINE_WARP_BWD)
+    nw = 0
+    for c in cases:
+        if c['kind'] != 'warp':
+            continue
+        i = c['id']
+        x = T(arr[f'w{i}_x']).to(DEV).requires_grad_(True)
+        y = W.affine_warp(x, T(arr[f'w{i}_theta']).to(DEV), *c['out'])
+        dx, = torch.autograd.grad([y], [x], [T(arr[f'w{i}_gy']).to(DEV)])
+        nw += 1
+        np.testing.assert_allclose(y.detach().cpu().numpy(), arr[f'w{i}_y'], rtol=1e-4, atol=3e-5, err_msg=str(c))
+        np.testing.assert_allclose(dx.cpu().numpy(), arr[f'w{i}_dx'], rtol=1e-4, atol=6e-5, err_msg=str(c))
+    assert native.launch_count(native.K_AFFINE_WARP_FWD) == k0[0] + nw and native.launch_count(native.K_AFFINE_WARP_BWD) == k0[1] + nw
+    rng = np.random.RandomState(4)
+    for (n, ch, hi, wi, ho, wo) in [(3, 4, 61, 47, 50, 70), (2, 3, 33, 33, 33, 33), (2, 1, 8, 100, 40, 9)]:
+        x = rng.randn(n, ch, hi, wi).astype(np.float32)
+        gy = rng.randn(n, ch, ho, wo).astype(np.float32)
+        ang = rng.uniform(-np.pi, np.pi, n)
+        sx, sy = np.exp2(rng.uniform(-1.2, 1.2, n)), np.exp2(rng.uniform(-1.2, 1.2, n))
+        th = np.stack([np.stack([sx * np.cos(ang), -sy * np.sin(ang), rng.uniform(-1.5, 1.5, n)], 1),
+                       np.stack([sx * np.sin(ang), sy * np.cos(ang), rng.uniform(-1.5, 1.5, n)], 1)], 1).astype(np.float32)
+        xg = T(x).to(DEV).requires_grad_(True)
+        y = W.affine_warp(xg, T(th).to(DEV), ho, wo)
+        dx, = torch.autograd.grad([y], [xg], [T(gy).to(DEV)], create_graph=True)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), oracle.affine_warp(x, th, ho, wo), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(dx.detach().cpu().numpy(), oracle.affine_warp_bwd(gy, th, hi, wi), rtol=1e-4, atol=2e-4)
+        # second order: d/d(gy) of <dx, v> is W v
+        v = torch.randn_like(dx)
+        gyt = T(gy).to(DEV).requires_grad_(True)
+        dx2, = torch.autograd.grad([W.affine_warp(xg, T(th).to(DEV), ho, wo)], [xg], [gyt], create_graph=True)
+        back, = torch.autograd.grad([(dx2 * v).sum()], [gyt])
+        np.testing.assert_allclose(back.cpu().numpy(), oracle.affine_warp(v.cpu().numpy(), th, ho, wo), rtol=1e-4, atol=1e-4)
+        # half precision storage
+        for dt in (torch.float16, torch.bfloat16):
+            yl = W.affine_warp(T(x).to(dt).to(DEV), T(th).to(DEV), ho, wo)
+            close_lowp(yl.float().cpu().numpy(), oracle.affine_warp(T(x).to(dt).float().numpy(), th, ho, wo), dt, 'warp lowp')
+    # bench shape: <W x, g> == <x, W^T g>
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn([8, 4, 620, 620], device=DEV, generator=g)
+    gy = torch.randn([8, 4, 548, 548], device=DEV, generator=g)
+    a = torch.linspace(-0.6, 0.6, 8, device=DEV)
+    th = torch.stack([torch.stack([1.1 * a.cos(), -0.9 * a.sin(), 0.05 * a], 1), torch.stack([1.1 * a.sin(), 0.9 * a.cos(), -0.1 * a], 1)], 1)
+    xr = x.clone().requires_grad_(True)
+    y = W.affine_warp(xr, th, 548, 548)
+    dx, = torch.autograd.grad([y], [xr], [gy])
+    lhs, rhs = float((y.detach().double() * gy.double()).sum()), float((x.double() * dx.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0) + 1e-2, (lhs, rhs)
+    ref = W.affine_warp(x, th, 548, 548, impl='ref')          # aten on the device
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.cpu().numpy(), rtol=1e-3, atol=1e-3)
+
+
+def test_channel_mix_golden_and_oracle(native, oracle):
+    M = op('channel_mix')
+    cases, arr = load_golden('warp')
+    k0 = native.launch_count(native.K_CHANNEL_MIX)
+    for c in cases:
+        if c['kind'] != 'mix':
+            continue
+        i, ch = c['id'], c['channels']
+        x, C = T(arr[f'm{i}_x']).to(DEV).requires_grad_(True), T(arr[f'm{i}_C']).to(DEV)
+        A = torch.eye(ch, device=DEV).repeat(x.shape[0], 1, 1)
+        A[:, :3, :3] = C[:, :3, :3]
+        t = torch.nn.functional.pad(C[:, :3, 3], [0, ch - 3])
+        y = M.channel_mix(x, A, t)
+        dx, = torch.autograd.grad([y], [x], [T(arr[f'm{i}_gy']).to(DEV)])
+        np.testing.assert_allclose(y.detach().cpu().numpy(), arr[f'm{i}_y'], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(dx.cpu().numpy(), arr[f'm{i}_dx'], rtol=1e-5, atol=1e-5)
+    assert native.launch_count(native.K_CHANNEL_MIX) == k0 + 4
+    rng = np.random.RandomState(6)
+    for shape, dt in [([5, 4, 256, 256], torch.float32), ([2, 3, 7, 9], torch.float32), ([3, 1, 33], torch.float32),
+                      ([2, 4, 64, 64], torch.float16), ([2, 2, 17], torch.bfloat16)]:
+        x = T(rng.randn(*shape).astype(np.float32)).to(dt)
+        A = rng.randn(shape[0], shape[1], shape[1]).astype(np.float32)
+        t = rng.randn(shape[0], shape[1]).astype(np.float32)
+        got = M.channel_mix(x.to(DEV), T(A).to(DEV), T(t).to(DEV))
+        assert got.dtype == dt and got.shape == x.shape
+        close_lowp(got.float().cpu().numpy(), oracle.channel_mix(x.float().numpy(), A, t), dt, str(shape))
+
+
 def test_profiling_hooks_report_kernel_time(native):
     B = op('bias_act')
     x = torch.randn([8, 64, 128, 128], device=DEV)

@@ -230,3 +230,27 @@ def test_translate_sample_ref_matches_reference():
         np.testing.assert_allclose(y.detach().numpy(), arr[f'c{i}_y'], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(dx.numpy(), arr[f'c{i}_dx'].reshape(x.shape), rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(dt.numpy(), arr[f'c{i}_dt'].reshape(-1, 2), rtol=1e-4, atol=1e-4)
+
+
+def test_affine_warp_and_channel_mix_ref_paths_match_reference():
+    """CPU tensors take the reference composition inside affine_warp / channel_mix (no native code without a GPU)."""
+    W, M = op('affine_warp'), op('channel_mix')
+    cases, arr = load_golden('warp')
+    for c in cases:
+        i = c['id']
+        if c['kind'] == 'warp':
+            x = T(arr[f'w{i}_x']).requires_grad_(True)
+            y = W.affine_warp(x, T(arr[f'w{i}_theta']), *c['out'])
+            dx, = torch.autograd.grad([y], [x], [T(arr[f'w{i}_gy'])])
+            np.testing.assert_allclose(y.detach().numpy(), arr[f'w{i}_y'], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(dx.numpy(), arr[f'w{i}_dx'], rtol=1e-5, atol=1e-6)
+        else:
+            x, C = T(arr[f'm{i}_x']).requires_grad_(True), T(arr[f'm{i}_C'])
+            ch = c['channels']
+            A = torch.eye(ch).repeat(x.shape[0], 1, 1)
+            A[:, :3, :3] = C[:, :3, :3]
+            t = torch.nn.functional.pad(C[:, :3, 3], [0, ch - 3])
+            y = M.channel_mix(x, A, t)
+            dx, = torch.autograd.grad([y], [x], [T(arr[f'm{i}_gy'])])
+            np.testing.assert_allclose(y.detach().numpy(), arr[f'm{i}_y'], rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(dx.numpy(), arr[f'm{i}_dx'], rtol=1e-5, atol=1e-5)

@@ -183,3 +183,28 @@ def test_translate_sample(oracle):
         np.testing.assert_allclose(dx, arr[f'c{i}_dx'].reshape(x.shape), rtol=1e-4, atol=1e-4, err_msg=str(c))
         np.testing.assert_allclose(dt, arr[f'c{i}_dt'].reshape(-1, 2), rtol=2e-3, atol=2e-3, err_msg=str(c))
     assert n == 4
+
+
+def test_affine_warp_and_channel_mix(oracle):
+    """ADA's resampling step (affine_grid + grid_sample, training/augment.py:376-377) and colour matrix (:403-406):
+    the oracle against the reference's own outputs and first-order input gradients."""
+    cases, arr = load_golden('warp')
+    for c in cases:
+        i = c['id']
+        if c['kind'] == 'warp':
+            x, th = arr[f'w{i}_x'], arr[f'w{i}_theta']
+            oh, ow = c['out']
+            np.testing.assert_allclose(oracle.affine_warp(x, th, oh, ow), arr[f'w{i}_y'], rtol=1e-4, atol=2e-5, err_msg=str(c))
+            np.testing.assert_allclose(oracle.affine_warp_bwd(arr[f'w{i}_gy'], th, x.shape[2], x.shape[3]), arr[f'w{i}_dx'],
+                                       rtol=1e-4, atol=5e-5, err_msg=str(c))
+            # float64 instantiation: same coordinates (float32 by construction), wider arithmetic
+            np.testing.assert_allclose(oracle.affine_warp(x.astype(np.float64), th, oh, ow), arr[f'w{i}_y'], rtol=1e-4, atol=2e-5)
+        else:
+            x, C = arr[f'm{i}_x'], arr[f'm{i}_C']
+            ch = c['channels']
+            A = np.tile(np.eye(ch, dtype=np.float32), [x.shape[0], 1, 1])
+            A[:, :3, :3] = C[:, :3, :3]
+            t = np.zeros([x.shape[0], ch], dtype=np.float32)
+            t[:, :3] = C[:, :3, 3]
+            np.testing.assert_allclose(oracle.channel_mix(x, A, t), arr[f'm{i}_y'], **F32_TOL)
+            np.testing.assert_allclose(oracle.channel_mix(arr[f'm{i}_gy'], np.ascontiguousarray(A.transpose(0, 2, 1))), arr[f'm{i}_dx'], **F32_TOL)
