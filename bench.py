@@ -154,7 +154,12 @@ def main():
     ap.add_argument('--ada-p', type=float, default=0.3)
     ap.add_argument('--ada-margin', default='side', choices=['side', 'fixed', 'sync'],
                     help='how AugmentPipe learns its padding margin: side-stream read-back (default), clamp bound, or blocking read-back as upstream')
-    ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark=True (MIOpen exhaustive find; minutes of warm-up on a fresh box)')
+    ap.add_argument('--miopen', default='tuned', choices=['tuned', 'immediate', 'find'],
+                    help='convolution solver selection: tuned = immediate mode over the find-db shipped in <package>/tuning/miopen '
+                         '(db hit -> measured-fastest solver, miss -> heuristics); immediate = heuristics only; find = exhaustive search '
+                         '(~14 min on a fresh box; writes the user db to --miopen-db-out)')
+    ap.add_argument('--miopen-find', action='store_true', help='same as --miopen find')
+    ap.add_argument('--miopen-db-out', default=None, help='with --miopen find: directory for MIOpen\'s user find-db / perf-db')
     ap.add_argument('--quiet', action='store_true')
     ap.add_argument('--layout', choices=['nhwc', 'nchw'], default='nhwc',
                     help='memory layout of the reduced-precision blocks (the reference\'s fp16_channels_last option): nhwc keeps MIOpen\'s '
@@ -166,6 +171,21 @@ def main():
     args = ap.parse_args()
     if args.batch_gpu is None:
         args.batch_gpu = 32
+    if args.miopen_find:
+        args.miopen = 'find'
+    # solver databases must be in place before the first convolution of the process
+    miopen_db = None
+    if args.miopen == 'tuned':
+        miopen_db = mod('tuning').use_tuned_miopen_db()
+        if miopen_db is None:
+            args.miopen = 'immediate'
+    elif args.miopen == 'find' and args.miopen_db_out:
+        os.makedirs(args.miopen_db_out, exist_ok=True)
+        os.environ['MIOPEN_USER_DB_PATH'] = os.path.abspath(args.miopen_db_out)
+    if 'MIOPEN_USER_DB_PATH' not in os.environ:
+        # immediate / find without the shipped results: an empty user db (the trainers would otherwise pick the tuned one up)
+        import tempfile
+        os.environ['MIOPEN_USER_DB_PATH'] = tempfile.mkdtemp(prefix='montage_miopen_empty_')
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -190,9 +210,9 @@ def main():
     mod('torch_utils.custom_ops').verbosity = 'none'
 
     trainer, workload = build_trainer(args, device, rank, world)
-    # MIOpen: immediate-mode solver selection unless asked otherwise; the loops' default (find mode, as upstream's
-    # cudnn.benchmark=True) costs minutes of search per fresh box and would dominate a short benchmark.
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    # MIOpen: the reference sets cudnn.benchmark=True (training_loop.py:124), i.e. find mode; an exhaustive search costs
+    # ~14 minutes on a fresh box, so the default replays the search results shipped under <package>/tuning/miopen.
+    torch.backends.cudnn.benchmark = args.miopen == 'find'
 
     def progress(msg):
         if rank == 0 and not args.quiet:
@@ -280,6 +300,8 @@ def main():
             'config': {'workload': workload + (' [TINY channel counts: smoke only]' if args.tiny else ''), 'global_batch': args.batch_gpu * world,
                        'batch_per_gpu': args.batch_gpu, 'layers': args.layers if args.workload == 'aio' else 1, 'resolution': args.res,
                        'layout': f'{args.layout} in the {args.dtype} blocks (fp16_channels_last)' if args.dtype != 'fp32' else 'nchw',
+                       'conv_solver_selection': {'tuned': 'MIOpen immediate mode over the find-db shipped in tuning/miopen', 'immediate': 'MIOpen immediate-mode heuristics',
+                                                 'find': 'MIOpen exhaustive find in this run'}[args.miopen],
                        'parallelism': f'dp{world} (one flat-buffer RCCL all-reduce per phase)',
                        'native_launches_per_step': {k: round((counts1[k] - counts0[k]) / args.steps, 1) for k in counts1 if counts1[k] - counts0[k]}},
             'roofline': roofline,

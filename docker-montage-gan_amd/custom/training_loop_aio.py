@@ -31,6 +31,7 @@ from ..torch_utils import training_stats
 from ..torch_utils.ops import conv2d_gradfix
 from ..torch_utils.ops import grid_sample_gradfix
 from ..training import phase_engine
+from .. import tuning
 
 renderer_config = {
     'img_resolution': 256,
@@ -120,6 +121,8 @@ class AioTrainer:
         np.random.seed(random_seed * num_gpus + rank)
         torch.manual_seed(random_seed * num_gpus + rank)
         torch.backends.cudnn.benchmark = True           # MIOpen find mode on ROCm
+        if torch.backends.cudnn.benchmark and 'MIOPEN_USER_DB_PATH' not in os.environ:
+            tuning.use_tuned_miopen_db(find_mode='FAST')       # replay the shipped search results instead of a 14-minute find
         conv2d_gradfix.enabled = True
         grid_sample_gradfix.enabled = True
 

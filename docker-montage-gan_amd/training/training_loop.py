@@ -21,6 +21,7 @@ from ..torch_utils import training_stats
 from ..torch_utils.ops import conv2d_gradfix
 from ..torch_utils.ops import grid_sample_gradfix
 from . import phase_engine
+from .. import tuning
 
 
 def default_kwargs(num_gpus=1, batch_gpu=32, resolution=256, img_channels=4, gamma=None, num_fp16_res=4,
@@ -61,6 +62,8 @@ class Trainer:
         np.random.seed(random_seed * num_gpus + rank)
         torch.manual_seed(random_seed * num_gpus + rank)
         torch.backends.cudnn.benchmark = cudnn_benchmark
+        if torch.backends.cudnn.benchmark and 'MIOPEN_USER_DB_PATH' not in os.environ:
+            tuning.use_tuned_miopen_db(find_mode='FAST')       # replay the shipped search results instead of a 14-minute find
         torch.backends.cuda.matmul.allow_tf32 = allow_tf32
         torch.backends.cudnn.allow_tf32 = allow_tf32
         conv2d_gradfix.enabled = True

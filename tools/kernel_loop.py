@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch ONE native kernel configuration a few times (for rocprofv3 --pmc runs).
-usage: kernel_loop.py <upfirdn2d|up2|down2|bias_act|calib4|epilogue|bwd_fused> <dtype> [iters]"""
+usage: kernel_loop.py <upfirdn2d|up2|down2|bias_act|calib4|epilogue|bwd_fused> <dtype> [iters] [nchw|nhwc]"""
 import importlib
 import os
 import sys
@@ -16,14 +16,15 @@ B = importlib.import_module(f'{PKG}.torch_utils.ops.bias_act')
 E = importlib.import_module(f'{PKG}.torch_utils.ops.modconv_epilogue')
 which, dt = sys.argv[1], getattr(torch, sys.argv[2])
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+fmt = torch.channels_last if (len(sys.argv) > 4 and sys.argv[4] == 'nhwc') else torch.contiguous_format
 dev = torch.device('cuda', 0)
 n, c, r = 32, 64, 256
 f = U.setup_filter([1, 3, 3, 1]).to(dev)
 if which == 'upfirdn2d':
-    x = torch.randn([n, c, r + 1, r + 1], device=dev).to(dt)
+    x = torch.randn([n, c, r + 1, r + 1], device=dev).to(dt).contiguous(memory_format=fmt)
     fn = lambda: U.upfirdn2d(x, f, padding=[1, 1, 1, 1], gain=4)
 elif which == 'bias_act':
-    x = torch.randn([n, c, r, r], device=dev).to(dt)
+    x = torch.randn([n, c, r, r], device=dev).to(dt).contiguous(memory_format=fmt)
     b = torch.randn([c], device=dev).to(dt)
     fn = lambda: B.bias_act(x, b, act='lrelu', clamp=256)
 elif which == 'calib4':
@@ -33,13 +34,13 @@ elif which == 'calib4':
     x = base[1:].reshape(n, c, r, r)
     fn = lambda: B.bias_act(x, None, act='lrelu')
 elif which == 'up2':
-    x = torch.randn([n, c, r // 2, r // 2], device=dev).to(dt)
+    x = torch.randn([n, c, r // 2, r // 2], device=dev).to(dt).contiguous(memory_format=fmt)
     fn = lambda: U.upfirdn2d(x, f, up=2, padding=[2, 1, 2, 1], gain=4)
 elif which == 'down2':
-    x = torch.randn([n, c, r, r], device=dev).to(dt)
+    x = torch.randn([n, c, r, r], device=dev).to(dt).contiguous(memory_format=fmt)
     fn = lambda: U.upfirdn2d(x, f, down=2, padding=[1, 1, 1, 1])
 elif which == 'bwd_fused':
-    x = torch.randn([n, c, r, r], device=dev).to(dt).requires_grad_(True)
+    x = torch.randn([n, c, r, r], device=dev).to(dt).contiguous(memory_format=fmt).requires_grad_(True)
     d = (torch.rand([n, c], device=dev) + 0.5).requires_grad_(True)
     nz = torch.randn([r, r], device=dev)
     b = torch.randn([c], device=dev).requires_grad_(True)
@@ -49,7 +50,7 @@ elif which == 'bwd_fused':
     torch.set_grad_enabled(True)
     fn = lambda: torch.autograd.grad([ye], [x, d, b, st], [gy], retain_graph=True)[0]
 else:
-    x = torch.randn([n, c, r, r], device=dev).to(dt)
+    x = torch.randn([n, c, r, r], device=dev).to(dt).contiguous(memory_format=fmt)
     d = torch.rand([n, c], device=dev) + 0.5
     nz = torch.randn([r, r], device=dev)
     b = torch.randn([c], device=dev)
