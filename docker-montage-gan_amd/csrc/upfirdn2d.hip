@@ -584,6 +584,101 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
     }
 }
 
+// up = down = 1 in channels-last: row streaming.  The lane walks DOWN its chunk one input row at a time; a row
+// meets tap ky of output row (row - ky), so a ring of FH accumulator vectors carries the vertical taps and every
+// input row is loaded exactly once per chunk (the block kernel above re-reads the FH-1 rows two consecutive
+// blocks share, and those re-reads partly miss L2: 1.49x read traffic measured).  The next row is requested
+// before the current one is consumed.
+template <class T>
+__global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UfParams p, NhwcGrid g)
+{
+    constexpr int VEC = NhwcVec<T>::VEC, FW = 4, FH = 4, ES = (int)sizeof(T);
+    constexpr unsigned BAD = 0x80000000u;
+
+    float ft[FH][FW];
+    #pragma unroll
+    for (int ky = 0; ky < FH; ky++)
+        #pragma unroll
+        for (int kx = 0; kx < FW; kx++) {
+            float v = 0.f;
+            if (kx < p.f_w && ky < p.f_h)
+                v = p.f[(p.flip ? ky : p.f_h - 1 - ky) * p.fs_h + (p.flip ? kx : p.f_w - 1 - kx) * p.fs_w];
+            ft[ky][kx] = v * p.gain;
+        }
+
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= g.total) return;
+    const uint32_t t1 = fd_div(t, g.cv_div), cvi = t - t1 * g.cv;
+    const uint32_t t2 = fd_div(t1, g.gx_div), gxi = t1 - t2 * g.gx;
+    const uint32_t n = fd_div(t2, g.chunk_div), chunk = t2 - n * g.nchunks;
+
+    const uint32_t in_bytes = (uint32_t)((int64_t)p.n * p.c * p.in_h * p.in_w * ES);
+    const uint32_t out_bytes = (uint32_t)((int64_t)p.n * p.c * p.out_h * p.out_w * ES);
+    const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)in_bytes, 0x00020000);
+    const auto rout = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)out_bytes, 0x00020000);
+
+    const int pix_bytes = p.c * ES;
+    const int ox = (int)gxi, ix0 = ox - p.padx0;
+    int col_off[FW];
+    #pragma unroll
+    for (int kx = 0; kx < FW; kx++) {
+        const int ix = ix0 + kx;
+        col_off[kx] = (ix >= 0 && ix < p.in_w) ? ix * pix_bytes + (int)cvi * 16 : -1;
+    }
+    const unsigned st_off = (unsigned)(ox * pix_bytes + (int)cvi * 16);             // ox < out_w by construction of the grid
+    const int in_pitch = p.in_w * pix_bytes, out_pitch = p.out_w * pix_bytes;
+    const int oy_begin = (int)(chunk * g.rows_per_chunk);
+    const int rows_out = min((int)g.rows_per_chunk, p.out_h - oy_begin), rows_in = rows_out + FH - 1;
+    int iy = oy_begin - p.pady0;
+    int in_row_off = ((int)n * p.in_h + iy) * in_pitch;
+    unsigned out_row_off = (unsigned)(((int)n * p.out_h + oy_begin - (FH - 1)) * out_pitch);      // row of output j - (FH-1) at j = 0
+
+    auto load_row = [&](u32x4_t (&dst)[FW]) {
+        const bool row_ok = iy >= 0 && iy < p.in_h;
+        #pragma unroll
+        for (int kx = 0; kx < FW; kx++) {
+            const unsigned off = (row_ok && col_off[kx] >= 0) ? (unsigned)(in_row_off + col_off[kx]) : BAD;
+            dst[kx] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
+        }
+        iy++; in_row_off += in_pitch;
+    };
+
+    float acc[FH][VEC];
+    #pragma unroll
+    for (int a = 0; a < FH; a++)
+        #pragma unroll
+        for (int e = 0; e < VEC; e++) acc[a][e] = 0.f;
+
+    u32x4_t cur[FW], nxt[FW];
+    load_row(cur);
+    for (int jb = 0; jb < rows_in; jb += FH) {
+        #pragma unroll
+        for (int r = 0; r < FH; r++) {
+            const int j = jb + r;
+            if (j >= rows_in) break;
+            if (j + 1 < rows_in) load_row(nxt);
+            float row[FW][VEC];
+            #pragma unroll
+            for (int kx = 0; kx < FW; kx++) nhwc_unpack<T>(cur[kx], row[kx]);
+            #pragma unroll
+            for (int ky = 0; ky < FH; ky++) {
+                const int slot = ((r - ky) % FH + FH) % FH;                         // output row j - ky
+                #pragma unroll
+                for (int kx = 0; kx < FW; kx++)
+                    #pragma unroll
+                    for (int e = 0; e < VEC; e++) acc[slot][e] = __builtin_fmaf(row[kx][e], ft[ky][kx], acc[slot][e]);
+            }
+            const int done = (r + 1) % FH;                                          // output row j - (FH-1) is complete
+            if (j >= FH - 1) __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack<T>(acc[done]), rout, out_row_off + st_off, 0, 0);
+            out_row_off += (unsigned)out_pitch;
+            #pragma unroll
+            for (int e = 0; e < VEC; e++) acc[done][e] = 0.f;
+            #pragma unroll
+            for (int kx = 0; kx < FW; kx++) cur[kx] = nxt[kx];
+        }
+    }
+}
+
 template <class T, int UP, int DN, int PX, int PY>
 void launch_nhwc_phase(const UfParams& p, hipStream_t s)
 {
@@ -596,7 +691,9 @@ void launch_nhwc_phase(const UfParams& p, hipStream_t s)
     g.nchunks = (uint32_t)((p.out_h + (int)g.rows_per_chunk - 1) / (int)g.rows_per_chunk);
     g.total = (uint32_t)p.n * g.nchunks * g.gx * g.cv;
     g.cv_div = make_fastdiv(g.cv); g.gx_div = make_fastdiv(g.gx); g.chunk_div = make_fastdiv(g.nchunks);
-    hipLaunchKernelGGL((upfirdn2d_nhwc<T, UP, DN, PX, PY, MX, MY>), dim3((g.total + 255u) / 256u), dim3(256), 0, s, p, g);
+    // tall images: row streaming (every input row read once per chunk); short ones: the block kernel (more parallel slack)
+    if (UP == 1 && DN == 1 && p.out_h >= 192) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T>), dim3((g.total + 255u) / 256u), dim3(256), 0, s, p, g);
+    else hipLaunchKernelGGL((upfirdn2d_nhwc<T, UP, DN, PX, PY, MX, MY>), dim3((g.total + 255u) / 256u), dim3(256), 0, s, p, g);
 }
 
 template <class T>

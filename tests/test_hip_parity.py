@@ -166,7 +166,7 @@ def test_upfirdn2d_nhwc_kernel_bit_exact_and_edges(native, oracle, dtype):
             (2, 1, [2, 1, 1, 2]), (2, 1, [3, 2, 1, 0]), (1, 2, [1, 1, 1, 1]), (1, 2, [0, 2, 2, 0]), (1, 2, [-1, 3, 2, 1])]
     before = native.launch_count(native.K_UPFIRDN2D_NHWC)
     ncalls = 0
-    for shape in ([2, vec, 37, 45], [1, 2 * vec, 70, 33], [2, 3 * vec, 8, 8], [1, vec, 131, 5]):
+    for shape in ([2, vec, 37, 45], [1, 2 * vec, 70, 33], [2, 3 * vec, 8, 8], [1, vec, 131, 5], [1, vec, 230, 9]):    # >= 192 rows: the row-streaming variant
         for up, down, pad in cfgs:
             for fk, tp in taps.items():
                 v = np.asarray(tp, dtype=np.float32)
