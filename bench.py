@@ -167,6 +167,7 @@ def main():
     ap.add_argument('--nhwc-1x1', choices=['matmul', 'conv'], default='conv', help='with nhwc: few-channel 1x1 convolutions straight to the convolution library (conv) or as the reference routes them around a cuDNN pitfall (matmul)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow)')
     ap.add_argument('--share-gpu', action='store_true', help='rehearsal only: every rank uses cuda:0')
+    ap.add_argument('--host-profile', default=None, help='path prefix: cProfile the host over the timed steps (diagnostic; perturbs the timing)')
     ap.add_argument('--marker-file', default=None, help='write clock readings at the start/end of the timed region (for cutting a rocprofv3 trace)')
     args = ap.parse_args()
     if args.batch_gpu is None:
@@ -235,14 +236,28 @@ def main():
 
     def clocks():
         return {n: time.clock_gettime_ns(getattr(time, n)) for n in ('CLOCK_MONOTONIC', 'CLOCK_BOOTTIME', 'CLOCK_REALTIME', 'CLOCK_MONOTONIC_RAW')}
+    host_prof = None
+    if args.host_profile and rank == 0:          # cProfile over the timed steps only (slows the host: not a benchmark number)
+        import cProfile
+        host_prof = cProfile.Profile()
+        host_prof.enable()
     mark0 = clocks()
     t0 = time.perf_counter()
     for i in range(args.steps):
         trainer.run_iteration()
         if (i + 1) % 4 == 0:
             progress(f'step {i + 1}/{args.steps} enqueued at +{time.perf_counter() - t0:.2f} s')
+    host_enqueue = time.perf_counter() - t0
     sync_all()
     elapsed = time.perf_counter() - t0
+    if host_prof is not None:
+        host_prof.disable()
+        import io
+        import pstats
+        for key in ('cumulative', 'tottime'):
+            buf = io.StringIO()
+            pstats.Stats(host_prof, stream=buf).sort_stats(key).print_stats(90)
+            open(f'{args.host_profile}_{key}.txt', 'w').write(buf.getvalue())
     progress(f'timed region: {elapsed:.2f} s')
     if args.marker_file and rank == 0:
         json.dump(dict(start=mark0, end=clocks(), steps=args.steps), open(args.marker_file, 'w'))
@@ -295,7 +310,7 @@ def main():
         out = {
             'metric': 'img/sec (full G+D step), 8-layer 256^2 RGBA' if args.workload == 'aio' else 'img/sec (full G+D step), single StyleGAN2 256^2 RGBA',
             'value': round(imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'host_enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': workload + (' [TINY channel counts: smoke only]' if args.tiny else ''), 'global_batch': args.batch_gpu * world,
                        'batch_per_gpu': args.batch_gpu, 'layers': args.layers if args.workload == 'aio' else 1, 'resolution': args.res,

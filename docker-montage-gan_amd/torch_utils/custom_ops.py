@@ -89,7 +89,7 @@ class _Upfirdn2dPlugin:
         _require(y.numel() <= 2 ** 31 - 1, 'output is too large')                              # :36
         if y.numel() == 0:
             return y
-        with torch.cuda.device(x.device):
+        with native.guard(x.device):
             rc = native.lib().mg_upfirdn2d(
                 native.ptr(x), native.ptr(f), native.ptr(y), native.dtype_code(x.dtype),
                 native.I32x4(n, c, ih, iw), native.I64x4(*x.stride()),
@@ -128,7 +128,7 @@ class _BiasActPlugin:
         has_b = not _is_null(b)
         if x.numel() == 0:
             return y
-        with torch.cuda.device(x.device):
+        with native.guard(x.device):
             rc = native.lib().mg_bias_act(
                 native.ptr(x), native.ptr(b if has_b else None),
                 native.ptr(None if _is_null(xref) else xref), native.ptr(None if _is_null(yref) else yref),

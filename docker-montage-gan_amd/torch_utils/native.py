@@ -139,7 +139,29 @@ def dtype_code(torch_dtype):
 def stream_ptr(device):
     """Handle of torch's CURRENT stream on `device` (the contract of the reference plugins, upfirdn2d.cpp:92)."""
     import torch
-    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    idx = device.index
+    return c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx))
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_no_guard = _NoGuard()
+
+
+def guard(device):
+    """``torch.cuda.device(device)`` only when `device` is not already the current one (the usual case: one process
+    per GPU) -- entering the real guard costs more host time than the launch it protects."""
+    import torch
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _no_guard
+    return torch.cuda.device(device)
 
 
 def ptr(t):

@@ -23,7 +23,7 @@ def _ref(x, theta, out_h, out_w):
 
 def _launch(fn, src, theta, dst, n, c, ih, iw, oh, ow):
     if src.numel() and dst.numel():
-        with torch.cuda.device(src.device):
+        with native.guard(src.device):
             native.check(fn(native.ptr(src), native.ptr(theta), native.ptr(dst), native.dtype_code(src.dtype), n, c, ih, iw, oh, ow,
                             native.stream_ptr(src.device)))
     elif dst.numel():

@@ -41,7 +41,7 @@ class _AlphaCompositeHip(torch.autograd.Function):
         b, l, c, h, w = x.shape
         x = x.contiguous()
         y = torch.empty([b, 4, h, w], dtype=x.dtype, device=x.device)
-        with torch.cuda.device(x.device):
+        with native.guard(x.device):
             native.check(native.lib().mg_alpha_composite_fwd(native.ptr(x), native.ptr(y), native.dtype_code(x.dtype),
                                                              b, l, h, w, native.stream_ptr(x.device)))
         ctx.save_for_backward(x)
@@ -54,7 +54,7 @@ class _AlphaCompositeHip(torch.autograd.Function):
         b, l, c, h, w = x.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with native.guard(x.device):
             native.check(native.lib().mg_alpha_composite_bwd(native.ptr(x), native.ptr(dy), native.ptr(dx),
                                                              native.dtype_code(x.dtype), b, l, h, w,
                                                              1 if ctx.safe_grad else 0, native.stream_ptr(x.device)))

@@ -141,7 +141,7 @@ def _bias_act_cuda(dim=1, act='linear', alpha=None, gain=None, clamp=None):
                     dx = torch.empty_like(dy)
                     # the channels-last kernel leaves per-sample partial sums [N, C]
                     acc = torch.zeros([n * c if nhwc else c], dtype=torch.float32, device=dy.device)
-                    with torch.cuda.device(dy.device):
+                    with native.guard(dy.device):
                         bwd = native.lib().mg_bwd_fused_nhwc if nhwc else native.lib().mg_bwd_fused
                         native.check(bwd(
                             native.ptr(dy), native.ptr(y if y.numel() else None), native.ptr(None), native.ptr(None), native.ptr(None),

@@ -26,7 +26,7 @@ class _Mix(torch.autograd.Function):
         x = x.contiguous()
         y = torch.empty_like(x)
         if x.numel():
-            with torch.cuda.device(x.device):
+            with native.guard(x.device):
                 native.check(native.lib().mg_channel_mix(native.ptr(x), native.ptr(A), native.ptr(t), native.ptr(y),
                                                          native.dtype_code(x.dtype), n, c, x.numel() // (n * c), native.stream_ptr(x.device)))
         ctx.save_for_backward(A)

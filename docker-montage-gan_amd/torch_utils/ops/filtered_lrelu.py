@@ -57,7 +57,7 @@ def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=np
     x = x.contiguous()
     y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device)
     bb = b.to(x.dtype).contiguous() if b is not None else None
-    with torch.cuda.device(x.device):
+    with native.guard(x.device):
         native.check(native.lib().mg_filtered_lrelu(
             native.ptr(x), native.ptr(bb), native.ptr(fu2), native.ptr(fd2), native.ptr(y), native.dtype_code(x.dtype),
             n, c, ih, iw, oh, ow, fu2.shape[0], fu2.shape[1], fd2.shape[0], fd2.shape[1], up, down, px0, py0,

@@ -85,7 +85,7 @@ def _epilogue_hip(act, alpha, gain, clamp):
             bb = b.detach().to(x.dtype).contiguous() if b is not None else None
             y = torch.empty_like(x)         # keeps the (dense) layout of x
             if x.numel():
-                with torch.cuda.device(x.device):
+                with native.guard(x.device):
                     fwd = native.lib().mg_fma_bias_act_nhwc if nhwc else native.lib().mg_fma_bias_act
                     native.check(fwd(
                         native.ptr(x), native.ptr(d32), native.ptr(nz32), native.ptr(bb), native.ptr(y),
@@ -138,7 +138,7 @@ def _epilogue_hip(act, alpha, gain, clamp):
             stride = ctx.noise_meta[2] if has_nz else 0
             d32 = dcoefs.to(x.dtype).to(torch.float32).contiguous() if has_d else None
             if x.numel():
-                with torch.cuda.device(x.device):
+                with native.guard(x.device):
                     bwd = native.lib().mg_bwd_fused_nhwc if nhwc else native.lib().mg_bwd_fused
                     native.check(bwd(
                         native.ptr(dy), native.ptr(None if ident else y), native.ptr(x if want_gd else None), native.ptr(d32),
@@ -191,7 +191,7 @@ class _ChannelScale(torch.autograd.Function):
         y = torch.empty_like(x)
         ctx.nhwc = nhwc
         if x.numel():
-            with torch.cuda.device(x.device):
+            with native.guard(x.device):
                 fwd = native.lib().mg_fma_bias_act_nhwc if nhwc else native.lib().mg_fma_bias_act
                 native.check(fwd(native.ptr(x), native.ptr(s32), native.ptr(None), native.ptr(None),
                                                           native.ptr(y), native.dtype_code(x.dtype), 1, 0.0, 1.0, -1.0, 1.0, native.ptr(None), 0,
@@ -213,7 +213,7 @@ class _ChannelScale(torch.autograd.Function):
         gd = torch.zeros([n * c], dtype=torch.float32, device=x.device) if want_ds else None
         s32 = s.to(x.dtype).to(torch.float32).contiguous()
         if x.numel():
-            with torch.cuda.device(x.device):
+            with native.guard(x.device):
                 bwd = native.lib().mg_bwd_fused_nhwc if ctx.nhwc else native.lib().mg_bwd_fused
                 native.check(bwd(native.ptr(dy), native.ptr(None), native.ptr(x if want_ds else None),
                                                        native.ptr(s32), native.ptr(None), native.ptr(dx), native.ptr(gd),

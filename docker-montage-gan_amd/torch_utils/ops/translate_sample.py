@@ -11,6 +11,7 @@ theta = [[1,0,t_x],[0,1,t_y]] with gradients w.r.t. both x and t (csrc/translate
 gather-only input gradient, block-reduced translation gradient).  ``impl='ref'`` / CPU
 tensors run the aten ops above.
 """
+import numpy as np
 import torch
 
 from .. import native
@@ -20,7 +21,7 @@ from .. import misc
 def translation_to_theta(t):
     """[..., 2] -> [..., 2, 3] = [[1,0,tx],[0,1,ty]]; what image_utils.convert_translate_to_2x3
     (:316-335) builds with a double python loop."""
-    eye = torch.tensor([[1., 0.], [0., 1.]], dtype=t.dtype, device=t.device).expand(*t.shape[:-1], 2, 2)
+    eye = misc.constant(np.eye(2), dtype=t.dtype, device=t.device).expand(*t.shape[:-1], 2, 2)      # cached: no host->device copy per call
     return torch.cat([eye, t.unsqueeze(-1)], dim=-1)
 
 
@@ -40,7 +41,7 @@ class _TranslateSampleHip(torch.autograd.Function):
         x = x.contiguous()
         t32 = t.detach().to(torch.float32).contiguous()
         y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with native.guard(x.device):
             native.check(native.lib().mg_translate_sample_fwd(native.ptr(x), native.ptr(t32), native.ptr(y),
                                                               native.dtype_code(x.dtype), m, c, h, w, float(shift),
                                                               native.stream_ptr(x.device)))
@@ -56,7 +57,7 @@ class _TranslateSampleHip(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dt = None
         L, code, s = native.lib(), native.dtype_code(x.dtype), native.stream_ptr(x.device)
-        with torch.cuda.device(x.device):
+        with native.guard(x.device):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 native.check(L.mg_translate_sample_bwd_input(native.ptr(dy), native.ptr(t32), native.ptr(dx), code,

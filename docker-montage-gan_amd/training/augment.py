@@ -247,14 +247,25 @@ class AugmentPipe(torch.nn.Module):
             else:
                 mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().to(torch.int32).tolist())   # the one host sync
             images = torch.nn.functional.pad(input=images, pad=[mx0, mx1, my0, my1], mode='reflect')
-            G_inv = translate2d((mx0 - mx1) / 2, (my0 - my1) / 2, device=dev) @ G_inv
             # x2 upsample with the 12-tap symlet (separable -> two native passes)
             images = upfirdn2d.upsample2d(x=images, f=self.Hz_geom, up=2)
-            G_inv = scale2d(2, 2, device=dev) @ G_inv @ scale2d_inv(2, 2, device=dev)
-            G_inv = translate2d(-0.5, -0.5, device=dev) @ G_inv @ translate2d_inv(-0.5, -0.5, device=dev)
             # sample on the output lattice
             shape = [n, ch, (height + hz_pad * 2) * 2, (width + hz_pad * 2) * 2]
-            G_inv = scale2d(2 / images.shape[3], 2 / images.shape[2], device=dev) @ G_inv @ scale2d_inv(2 / shape[3], 2 / shape[2], device=dev)
+            # Upstream chains six small matrix products around G_inv here (:365-375): shift by the padding, x2 scale,
+            # half-pixel shift, normalisation to [-1,1].  All of those factors are host-known constants of this call,
+            # so they are multiplied on the host (same order, float32) into ONE left and ONE right factor and uploaded
+            # without a blocking copy; per-call host->device constants would drain the launch queue four times.
+            f32 = np.float32
+
+            def T(tx, ty):
+                return np.asarray([[1, 0, tx], [0, 1, ty], [0, 0, 1]], dtype=f32)
+
+            def S(sx, sy):
+                return np.asarray([[sx, 0, 0], [0, sy, 0], [0, 0, 1]], dtype=f32)
+            left = S(2 / images.shape[3], 2 / images.shape[2]) @ (T(-0.5, -0.5) @ (S(2, 2) @ T((mx0 - mx1) / 2, (my0 - my1) / 2)))
+            right = (S(1 / 2, 1 / 2) @ T(0.5, 0.5)) @ S(1 / (2 / shape[3]), 1 / (2 / shape[2]))
+            lr = misc.upload_small(np.stack([left, right]), dev)
+            G_inv = lr[0] @ G_inv @ lr[1]
             images = affine_warp.affine_warp(images, G_inv[:, :2, :], shape[2], shape[3])     # affine_grid + grid_sample, one pass
             # back down, cropping the filter margin
             images = upfirdn2d.downsample2d(x=images, f=self.Hz_geom, down=2, padding=-hz_pad * 2, flip_filter=True)

@@ -25,6 +25,7 @@ from ..torch_utils.ops import conv2d_resample
 from ..torch_utils.ops import fma
 from ..torch_utils.ops import modconv_epilogue
 from ..torch_utils.ops import upfirdn2d
+from . import weight_prep
 
 # Module switch: use the fused epilogue op inside SynthesisLayer (GPU tensors only).
 fused_epilogue = True
@@ -69,7 +70,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     if not fused_modconv:
         # modulation: native one-pass scale on the GPU (its backward is one pass as well), aten otherwise
         x = modconv_epilogue.channel_scale(x, styles)
-        x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down,
+        x = conv2d_resample.conv2d_resample(x=x, w=weight_prep.get(weight, 1, x.dtype), f=resample_filter, up=up, down=down,
                                             padding=padding, flip_weight=flip_weight)
         if demodulate and noise is not None:
             x = fma.fma(x, dcoefs.to(x.dtype).reshape(n, -1, 1, 1), noise.to(x.dtype))
@@ -102,13 +103,25 @@ class FullyConnectedLayer(torch.nn.Module):
         self.weight_gain = lr_multiplier / np.sqrt(in_features)
         self.bias_gain = lr_multiplier
 
+    def prep_entries(self, dtype=torch.float32):
+        ents = [(self.weight, self.weight_gain, dtype)]
+        if self.bias is not None and self.bias_gain != 1:
+            ents.append((self.bias, self.bias_gain, dtype))
+        return ents
+
     def forward(self, x):
-        w = self.weight.to(x.dtype) * self.weight_gain
+        if x.dtype == self.weight.dtype:
+            w = weight_prep.get(self.weight, self.weight_gain, x.dtype)
+        else:
+            w = self.weight.to(x.dtype) * self.weight_gain
         b = self.bias
         if b is not None:
-            b = b.to(x.dtype)
-            if self.bias_gain != 1:
-                b = b * self.bias_gain
+            if self.bias_gain != 1 and x.dtype == b.dtype:
+                b = weight_prep.get(b, self.bias_gain, x.dtype)
+            else:
+                b = b.to(x.dtype)
+                if self.bias_gain != 1:
+                    b = b * self.bias_gain
         if self.activation == 'linear' and b is not None:
             return torch.addmm(b.unsqueeze(0), x, w.t())
         return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
@@ -140,10 +153,16 @@ class Conv2dLayer(torch.nn.Module):
             else:
                 self.bias = None
 
+    def prep_entries(self, dtype):
+        ents = [(self.weight, self.weight_gain, dtype)]
+        if self.bias is not None and dtype != torch.float32 and isinstance(self.bias, torch.nn.Parameter):
+            ents.append((self.bias, 1, dtype))
+        return ents
+
     def forward(self, x, gain=1):
-        w = self.weight * self.weight_gain
-        b = self.bias.to(x.dtype) if self.bias is not None else None
-        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
+        w = weight_prep.get(self.weight, self.weight_gain, x.dtype)           # (weight * weight_gain).to(x.dtype)
+        b = weight_prep.get(self.bias, 1, x.dtype) if self.bias is not None else None        # bias.to(x.dtype)
+        x = conv2d_resample.conv2d_resample(x=x, w=w, f=self.resample_filter, up=self.up, down=self.down,
                                             padding=self.padding, flip_weight=(self.up == 1))
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return bias_act.bias_act(x, b, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
@@ -168,18 +187,26 @@ class MappingNetwork(torch.nn.Module):
                                                           lr_multiplier=lr_multiplier))
         if num_ws is not None and w_avg_beta is not None:
             self.register_buffer('w_avg', torch.zeros([w_dim * _num_splits]))
+        self._prep = None
+
+    def prep_entries(self):
+        layers = ([self.embed] if self.c_dim > 0 else []) + [getattr(self, f'fc{idx}') for idx in range(self.num_layers)]
+        return [e for layer in layers for e in layer.prep_entries()]
 
     def forward(self, z, c=None, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
-        x = None
-        if self.z_dim > 0:
-            misc.assert_shape(z, [None, self.z_dim])
-            x = normalize_2nd_moment(z.to(torch.float32))
-        if self.c_dim > 0:
-            misc.assert_shape(c, [None, self.c_dim])
-            y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
-            x = torch.cat([x, y], dim=1) if x is not None else y
-        for idx in range(self.num_layers):
-            x = getattr(self, f'fc{idx}')(x)
+        if self._prep is None:
+            self._prep = weight_prep.Plan(self.prep_entries())
+        with weight_prep.scope(self._prep):
+            x = None
+            if self.z_dim > 0:
+                misc.assert_shape(z, [None, self.z_dim])
+                x = normalize_2nd_moment(z.to(torch.float32))
+            if self.c_dim > 0:
+                misc.assert_shape(c, [None, self.c_dim])
+                y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
+                x = torch.cat([x, y], dim=1) if x is not None else y
+            for idx in range(self.num_layers):
+                x = getattr(self, f'fc{idx}')(x)
         if self.w_avg_beta is not None and self.training and not skip_w_avg_update:
             self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
         if self.num_ws is not None:
@@ -257,7 +284,8 @@ class SynthesisLayer(torch.nn.Module):
                 st = st / st.norm(float('inf'), dim=1, keepdim=True)
             dcoefs = _demod_coefs(weight, st)
             y = modconv_epilogue.channel_scale(x, st)
-            y = conv2d_resample.conv2d_resample(x=y, w=weight.to(x.dtype), f=self.resample_filter, up=self.up,
+            wc = weight_prep.get(weight, 1, x.dtype) if weight is self.weight else weight.to(x.dtype)
+            y = conv2d_resample.conv2d_resample(x=y, w=wc, f=self.resample_filter, up=self.up,
                                                 padding=self.padding, flip_weight=flip_weight)
             if y.is_contiguous() or modconv_epilogue._is_nhwc(y):
                 return modconv_epilogue.modconv_epilogue(y, dcoefs, noise_raw, self.bias, act=self.activation, gain=act_gain,
@@ -288,7 +316,7 @@ class ToRGBLayer(torch.nn.Module):
     def forward(self, x, w, fused_modconv=True):
         styles = self.affine(w) * self.weight_gain
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
-        return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
+        return bias_act.bias_act(x, weight_prep.get(self.bias, 1, x.dtype), clamp=self.conv_clamp)
 
 
 class SynthesisBlock(torch.nn.Module):
@@ -323,6 +351,21 @@ class SynthesisBlock(torch.nn.Module):
         if in_channels != 0 and architecture == 'resnet':
             self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2, resample_filter=resample_filter,
                                     channels_last=self.channels_last)
+
+    def prep_entries(self, force_fp32=False):
+        dtype = self.fp16_dtype if self.use_fp16 and not force_fp32 else torch.float32
+        ents = []
+        for name in ('conv0', 'conv1', 'torgb'):
+            layer = getattr(self, name, None)
+            if layer is not None:
+                ents += layer.affine.prep_entries()
+                if dtype not in (torch.float32, torch.float16):         # fp16 renormalises the weight first (:58-61)
+                    ents.append((layer.weight, 1, dtype))
+                if dtype != torch.float32 and name == 'torgb':
+                    ents.append((layer.bias, 1, dtype))
+        if hasattr(self, 'skip'):
+            ents += self.skip.prep_entries(dtype)
+        return ents
 
     def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, **layer_kwargs):
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
@@ -383,17 +426,23 @@ class SynthesisNetwork(torch.nn.Module):
                                    use_fp16=(res >= fp16_resolution), conv_config_index=conv_config_index, **block_kwargs)
             self.num_ws += block.num_conv + (block.num_torgb if res == img_resolution else 0)
             setattr(self, f'b{res}', block)
+        self._prep = {}          # force_fp32 -> weight_prep entries (static per network)
 
     def forward(self, ws, **block_kwargs):
         misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
         ws = ws.to(torch.float32)
         x = img = None
         w_idx = 0
-        for res in self.block_resolutions:
-            block = getattr(self, f'b{res}')
-            # a block's toRGB shares the w of the next block's first conv
-            x, img = block(x, img, ws.narrow(1, w_idx, block.num_conv + block.num_torgb), **block_kwargs)
-            w_idx += block.num_conv
+        force_fp32 = bool(block_kwargs.get('force_fp32', False))
+        entries = self._prep.get(force_fp32)
+        if entries is None:
+            entries = self._prep[force_fp32] = weight_prep.Plan([e for res in self.block_resolutions for e in getattr(self, f'b{res}').prep_entries(force_fp32)])
+        with weight_prep.scope(entries):
+            for res in self.block_resolutions:
+                block = getattr(self, f'b{res}')
+                # a block's toRGB shares the w of the next block's first conv
+                x, img = block(x, img, ws.narrow(1, w_idx, block.num_conv + block.num_torgb), **block_kwargs)
+                w_idx += block.num_conv
         return img
 
 
@@ -455,6 +504,11 @@ class DiscriminatorBlock(torch.nn.Module):
             self.skip = Conv2dLayer(tmp_channels, out_channels, kernel_size=1, bias=False, down=2, trainable=next_trainable(),
                                     resample_filter=resample_filter, channels_last=self.channels_last)
 
+    def prep_entries(self, force_fp32=False):
+        dtype = self.fp16_dtype if self.use_fp16 and not force_fp32 else torch.float32
+        return [e for name in ('fromrgb', 'conv0', 'conv1', 'skip') if hasattr(self, name)
+                for e in getattr(self, name).prep_entries(dtype) if isinstance(getattr(self, name).weight, torch.nn.Parameter)]
+
     def forward(self, x, img, force_fp32=False):
         dtype = self.fp16_dtype if self.use_fp16 and not force_fp32 else torch.float32
         fmt = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
@@ -514,6 +568,12 @@ class DiscriminatorEpilogue(torch.nn.Module):
         self.fc = FullyConnectedLayer(in_channels * (self.init_res[0] * self.init_res[1]), in_channels, activation=activation)
         self.out = FullyConnectedLayer(in_channels, 1 if cmap_dim == 0 else cmap_dim)
 
+    def prep_entries(self):
+        ents = self.conv.prep_entries(torch.float32) + self.fc.prep_entries() + self.out.prep_entries()
+        if self.architecture == 'skip':
+            ents += self.fromrgb.prep_entries(torch.float32)
+        return ents
+
     def forward(self, x, img, cmap, force_fp32=False):
         misc.assert_shape(x, [None, self.in_channels, *self.init_res])
         x = x.to(dtype=torch.float32, memory_format=torch.contiguous_format)
@@ -562,10 +622,16 @@ class Discriminator(torch.nn.Module):
             self.mapping = MappingNetwork(z_dim=0, c_dim=c_dim, w_dim=cmap_dim, num_ws=None, w_avg_beta=None, **(mapping_kwargs or {}))
         self.b4 = DiscriminatorEpilogue(channels[base], cmap_dim=cmap_dim, resolution=base, init_res=self.init_res,
                                         **(epilogue_kwargs or {}), **common)
+        self._prep = {}
 
     def forward(self, img, c=None, **block_kwargs):
         x = None
-        for res in self.block_resolutions:
-            x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
-        cmap = self.mapping(None, c) if self.c_dim > 0 else None
-        return self.b4(x, img, cmap)
+        force_fp32 = bool(block_kwargs.get('force_fp32', False))
+        entries = self._prep.get(force_fp32)
+        if entries is None:
+            entries = self._prep[force_fp32] = weight_prep.Plan([e for res in self.block_resolutions for e in getattr(self, f'b{res}').prep_entries(force_fp32)] + self.b4.prep_entries())
+        with weight_prep.scope(entries):
+            for res in self.block_resolutions:
+                x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
+            cmap = self.mapping(None, c) if self.c_dim > 0 else None
+            return self.b4(x, img, cmap)

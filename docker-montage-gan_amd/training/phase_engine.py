@@ -47,6 +47,7 @@ class GradSync:
 
     def __init__(self, world_size=1, process_group=None):
         self.world_size, self.process_group = world_size, process_group
+        self._agreed = set()      # gradient signatures all ranks were seen to share
 
     @torch.no_grad()
     def __call__(self, params):
@@ -54,12 +55,21 @@ class GradSync:
         if self.world_size > 1:
             # Every rank runs the same phase code, so the SAME parameters carry gradients everywhere (a phase that
             # computes nothing -- global_Greg upstream -- leaves them all None and Adam skips them, as on one GPU).
-            # One tiny all-reduce checks that before the big one; a mismatch would otherwise hang or mis-add.
-            sig = torch.tensor([len(grads), sum(g.numel() for g in grads)], dtype=torch.int64, device=self._device(params))
-            lo, hi = sig.clone(), sig.clone()
-            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
-            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=self.process_group)
-            if not torch.equal(lo, hi):
+            # One tiny all-reduce checks that before the big one; a mismatch would otherwise hang or mis-add.  Which
+            # parameters get a gradient is a property of the phase's code path, not of the data, so each distinct
+            # signature is verified once (the comparison reads the result back, i.e. it drains the launch queue:
+            # doing it every phase would serialise host and device 36 times per step).
+            key = (len(params), len(grads), sum(g.numel() for g in grads))
+            agree = key in self._agreed
+            if not agree:
+                sig = torch.tensor(key[1:], dtype=torch.int64, device=self._device(params))
+                lo, hi = sig.clone(), sig.clone()
+                torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
+                torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=self.process_group)
+                agree = torch.equal(lo, hi)
+                if agree:
+                    self._agreed.add(key)
+            if not agree:
                 # ranks disagree: fall back to the union, missing gradients count as zeros
                 grads = []
                 for p in params:

@@ -156,6 +156,49 @@ def test_channels_last_blocks_match_nchw_blocks(dtype, one_by_one):
         CR.nhwc_1x1_workaround = True
 
 
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_batched_weight_preparation_matches_per_layer_expressions(channels_last):
+    """training/weight_prep.py: all `weight * gain`, `.to(dtype)` of a network in a few multi-tensor launches behind
+    one autograd node -- images, logits, first-order gradients and the path-length style double backward must equal
+    the per-layer expressions (bit for bit in the forward pass; gradients up to the order of float atomics)."""
+    NW, WP = mod('training.networks'), mod('training.weight_prep')
+    torch.manual_seed(2)
+    kw = dict(w_dim=64, img_resolution=64, img_channels=4, channel_base=2048, channel_max=64, conv_clamp=256, num_fp16_res=3,
+              fp16_dtype=torch.bfloat16, fp16_channels_last=channels_last)
+    G = NW.Generator(z_dim=64, mapping_kwargs=dict(num_layers=3), synthesis_kwargs={k: v for k, v in kw.items() if k not in ('w_dim', 'img_resolution', 'img_channels')},
+                     w_dim=64, img_resolution=64, img_channels=4).to(DEV).train()
+    D = NW.Discriminator(c_dim=0, img_resolution=64, img_channels=4, channel_base=2048, channel_max=64, conv_clamp=256, num_fp16_res=3,
+                         block_kwargs=dict(fp16_dtype=torch.bfloat16, fp16_channels_last=channels_last)).to(DEV).train()
+    z = torch.randn([4, 64], device=DEV)
+    res = []
+    try:
+        for on in (False, True):
+            WP.enabled = on
+            for p in list(G.parameters()) + list(D.parameters()):
+                p.grad = None
+            ws = G.mapping(z, None, skip_w_avg_update=True)
+            img = G.synthesis(ws, noise_mode='const')
+            logits = D(img, None)
+            torch.nn.functional.softplus(-logits).mean().backward()
+            first = [img.detach().clone(), logits.detach().clone()] + [p.grad.clone() for p in list(G.parameters()) + list(D.parameters()) if p.grad is not None]
+            # path-length style: gradient of the image w.r.t. ws with create_graph, then backward through it
+            for p in G.parameters():
+                p.grad = None
+            ws = G.mapping(z, None, skip_w_avg_update=True)
+            img = G.synthesis(ws, noise_mode='const')
+            gw, = torch.autograd.grad([(img * torch.ones_like(img)).sum()], [ws], create_graph=True)
+            gw.square().sum(2).mean(1).sqrt().mean().backward()
+            second = [p.grad.clone() for p in G.parameters() if p.grad is not None]
+            res.append(first + second)
+    finally:
+        WP.enabled = True
+    assert len(res[0]) == len(res[1])
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])      # forward: same arithmetic, deterministic kernels
+    for a, b in zip(res[0][2:], res[1][2:]):
+        # gradients pass through float atomics (split-K weight gradients in MIOpen, the fused reductions here): equal up to their order
+        assert float((a.float() - b.float()).norm()) <= 2e-3 * float(b.float().norm()) + 1e-12
+
+
 def test_aio_iteration_runs_native_and_updates_weights():
     """One full (tiny) train_aio iteration on the GPU: every phase fires at batch_idx 0; the native kernels
     run; weights move; a second iteration skips the lazy-regularisation phases."""
