@@ -78,27 +78,37 @@ class _Upfirdn2dPlugin:
         _require(upx >= 1 and upy >= 1, 'upsampling factor must be at least 1')                # :27
         _require(downx >= 1 and downy >= 1, 'downsampling factor must be at least 1')          # :28
         n, c, ih, iw = x.shape
+        key = (n, c, ih, iw, x.stride(), f.shape[0], f.shape[1], f.stride(), upx, upy, downx, downy, padx0, padx1, pady0, pady1)
+        plan = _uf_plans.get(key)
+        if plan is None:
+            def cdiv(a, b):  # C integer division truncates toward zero (upfirdn2d.cpp:32-33)
+                return int(a / b) if a * b < 0 else a // b
 
-        def cdiv(a, b):  # C integer division truncates toward zero (upfirdn2d.cpp:32-33)
-            return int(a / b) if a * b < 0 else a // b
-
-        ow = cdiv(iw * upx + padx0 + padx1 - f.size(1) + downx, downx)
-        oh = cdiv(ih * upy + pady0 + pady1 - f.size(0) + downy, downy)
-        _require(ow >= 1 and oh >= 1, 'output must be at least 1x1')                           # :34
-        y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device, memory_format=_suggest_memory_format(x))
-        _require(y.numel() <= 2 ** 31 - 1, 'output is too large')                              # :36
+            ow = cdiv(iw * upx + padx0 + padx1 - f.size(1) + downx, downx)
+            oh = cdiv(ih * upy + pady0 + pady1 - f.size(0) + downy, downy)
+            _require(ow >= 1 and oh >= 1, 'output must be at least 1x1')                       # :34
+            _require(n * c * oh * ow <= 2 ** 31 - 1, 'output is too large')                    # :36
+            fmt = _suggest_memory_format(x)
+            ys = torch.empty([n, c, oh, ow], dtype=torch.uint8, device='meta', memory_format=fmt).stride()
+            plan = (oh, ow, fmt, native.I32x4(n, c, ih, iw), native.I64x4(*x.stride()), native.I32x2(f.size(0), f.size(1)),
+                    native.I64x2(*f.stride()), native.I32x4(n, c, oh, ow), native.I64x4(*ys),
+                    int(upx), int(upy), int(downx), int(downy), int(padx0), int(pady0))
+            if len(_uf_plans) < 4096:
+                _uf_plans[key] = plan
+        oh, ow, fmt = plan[0], plan[1], plan[2]
+        y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device, memory_format=fmt)
         if y.numel() == 0:
             return y
         with native.guard(x.device):
             rc = native.lib().mg_upfirdn2d(
-                native.ptr(x), native.ptr(f), native.ptr(y), native.dtype_code(x.dtype),
-                native.I32x4(n, c, ih, iw), native.I64x4(*x.stride()),
-                native.I32x2(f.size(0), f.size(1)), native.I64x2(*f.stride()),
-                native.I32x4(n, c, oh, ow), native.I64x4(*y.stride()),
-                int(upx), int(upy), int(downx), int(downy), int(padx0), int(pady0), 1 if flip else 0, float(gain),
-                native.stream_ptr(x.device))
-        native.check(rc)
+                x.data_ptr(), f.data_ptr(), y.data_ptr(), native.dtype_code(x.dtype), *plan[3:],
+                1 if flip else 0, float(gain), native.stream_ptr(x.device))
+        if rc:
+            native.check(rc)
         return y
+
+
+_uf_plans = dict()
 
 
 class _BiasActPlugin:
@@ -106,37 +116,45 @@ class _BiasActPlugin:
 
     @staticmethod
     def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
+        has_b, has_xref, has_yref, has_dy = not _is_null(b), not _is_null(xref), not _is_null(yref), not _is_null(dy)
         _require(x.is_cuda, 'x must reside on CUDA device')                                    # bias_act.cpp:35
-        _require(_is_null(b) or (b.dtype == x.dtype and b.device == x.device),
+        _require(not has_b or (b.dtype == x.dtype and b.device == x.device),
                  'b must have the same dtype and device as x')                                 # :36
-        for t, name in ((xref, 'xref'), (yref, 'yref')):
-            _require(_is_null(t) or (t.shape == x.shape and t.dtype == x.dtype and t.device == x.device),
-                     f'{name} must have the same shape, dtype, and device as x')               # :37-38
-        _require(_is_null(dy) or (dy.shape == x.shape and dy.dtype == x.dtype and dy.device == x.device),
-                 'dy must have the same dtype and device as x')                                # :39
-        _require(x.numel() <= 2 ** 31 - 1, 'x is too large')                                   # :40
+        if has_xref:
+            _require(xref.shape == x.shape and xref.dtype == x.dtype and xref.device == x.device,
+                     'xref must have the same shape, dtype, and device as x')                  # :37
+        if has_yref:
+            _require(yref.shape == x.shape and yref.dtype == x.dtype and yref.device == x.device,
+                     'yref must have the same shape, dtype, and device as x')                  # :38
+        if has_dy:
+            _require(dy.shape == x.shape and dy.dtype == x.dtype and dy.device == x.device,
+                     'dy must have the same dtype and device as x')                            # :39
+        size_x = x.numel()
+        _require(size_x <= 2 ** 31 - 1, 'x is too large')                                      # :40
         _require(b is None or b.dim() == 1, 'b must have rank 1')                              # :41
-        _require(_is_null(b) or (0 <= dim < x.dim()), 'dim is out of bounds')                  # :42
-        _require(_is_null(b) or b.numel() == x.size(dim), 'b has wrong number of elements')    # :43
+        if has_b:
+            _require(0 <= dim < x.dim(), 'dim is out of bounds')                               # :42
+            _require(b.numel() == x.size(dim), 'b has wrong number of elements')               # :43
+            _require(b.is_contiguous(), 'b must be contiguous')                                # :48
         _require(grad >= 0, 'grad must be non-negative')                                       # :44
         _require(_is_non_overlapping_and_dense(x), 'x must be non-overlapping and dense')      # :47
-        _require(_is_null(b) or b.is_contiguous(), 'b must be contiguous')                     # :48
-        for t, name in ((xref, 'xref'), (yref, 'yref'), (dy, 'dy')):
-            _require(_is_null(t) or _has_same_layout(t, x), f'{name} must have the same layout as x')  # :49-51
+        xs = x.stride()
+        for t, name, has in ((xref, 'xref', has_xref), (yref, 'yref', has_yref), (dy, 'dy', has_dy)):
+            # same shape (checked above) + same strides = same layout; the slow path handles size-1 dims (:16-28)
+            _require(not has or t.stride() == xs or _has_same_layout(t, x), f'{name} must have the same layout as x')  # :49-51
         y = torch.empty_like(x)
-        _require(_has_same_layout(y, x), 'y must have the same layout as x')                   # :56
-        has_b = not _is_null(b)
-        if x.numel() == 0:
+        _require(y.stride() == xs or _has_same_layout(y, x), 'y must have the same layout as x')   # :56
+        if size_x == 0:
             return y
         with native.guard(x.device):
             rc = native.lib().mg_bias_act(
-                native.ptr(x), native.ptr(b if has_b else None),
-                native.ptr(None if _is_null(xref) else xref), native.ptr(None if _is_null(yref) else yref),
-                native.ptr(None if _is_null(dy) else dy), native.ptr(y), native.dtype_code(x.dtype),
+                x.data_ptr(), b.data_ptr() if has_b else None, xref.data_ptr() if has_xref else None,
+                yref.data_ptr() if has_yref else None, dy.data_ptr() if has_dy else None, y.data_ptr(), native.dtype_code(x.dtype),
                 int(grad), int(act), float(alpha), float(gain), float(clamp),
-                x.numel(), b.numel() if has_b else 0, x.stride(dim) if has_b else 1,
+                size_x, b.numel() if has_b else 0, x.stride(dim) if has_b else 1,
                 native.stream_ptr(x.device))
-        native.check(rc)
+        if rc:
+            native.check(rc)
         return y
 
 

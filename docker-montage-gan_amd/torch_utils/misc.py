@@ -10,10 +10,17 @@ import numpy as np
 import torch
 
 _constant_cache = dict()
+_constant_fast = dict()
 
 
 def constant(value, shape=None, dtype=None, device=None, memory_format=None):
     """Cached constant tensor: avoids a host->device copy per use (misc.py:22-43)."""
+    fast = None
+    if type(value) in (int, float):       # python scalars (ADA's matrix entries): skip the array round trip for the key
+        fast = (value, type(value), shape if shape is None else tuple(shape), dtype, device, memory_format)
+        hit = _constant_fast.get(fast)
+        if hit is not None:
+            return hit
     value = np.asarray(value)
     shape = None if shape is None else tuple(shape)
     dtype = dtype or torch.get_default_dtype()
@@ -27,6 +34,8 @@ def constant(value, shape=None, dtype=None, device=None, memory_format=None):
             hit = hit.broadcast_to(shape)
         hit = hit.contiguous(memory_format=memory_format)
         _constant_cache[key] = hit
+    if fast is not None and len(_constant_fast) < 65536:
+        _constant_fast[fast] = hit
     return hit
 
 

@@ -138,9 +138,8 @@ def dtype_code(torch_dtype):
 
 def stream_ptr(device):
     """Handle of torch's CURRENT stream on `device` (the contract of the reference plugins, upfirdn2d.cpp:92)."""
-    import torch
     idx = device.index
-    return c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx))
+    return _raw_stream(_current_device() if idx is None else idx)
 
 
 class _NoGuard:
@@ -157,12 +156,27 @@ _no_guard = _NoGuard()
 def guard(device):
     """``torch.cuda.device(device)`` only when `device` is not already the current one (the usual case: one process
     per GPU) -- entering the real guard costs more host time than the launch it protects."""
-    import torch
     idx = device.index
-    if idx is None or idx == torch.cuda.current_device():
+    if idx is None or idx == _current_device():
         return _no_guard
+    import torch
     return torch.cuda.device(device)
 
 
+def _raw_stream(idx):
+    import torch
+    global _raw_stream, _current_device
+    _raw_stream, _current_device = torch._C._cuda_getCurrentRawStream, torch.cuda.current_device     # bind once
+    return _raw_stream(idx)
+
+
+def _current_device():
+    import torch
+    global _raw_stream, _current_device
+    _raw_stream, _current_device = torch._C._cuda_getCurrentRawStream, torch.cuda.current_device
+    return _current_device()
+
+
 def ptr(t):
-    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+    """Device address as a plain int (None -> NULL); ctypes converts it for the c_void_p parameters."""
+    return t.data_ptr() if t is not None else None

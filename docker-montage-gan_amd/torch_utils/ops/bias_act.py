@@ -150,7 +150,12 @@ def _bias_act_cuda(dim=1, act='linear', alpha=None, gain=None, clamp=None):
                     db = acc.reshape(n, c).sum(0) if nhwc else acc
                     return (dx if ctx.needs_input_grad[0] else None), db.to(dy.dtype)
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-                dx = dy if is_identity else BiasActCudaGrad.apply(dy, x, b, y)
+                if is_identity:
+                    dx = dy
+                elif torch.is_grad_enabled():
+                    dx = BiasActCudaGrad.apply(dy, x, b, y)
+                else:       # plain backward: the gradient kernel without another autograd node
+                    dx = _plugin.bias_act(dy, b, x, y, _null_tensor, 1, dim, idx, alpha, gain, clamp)
             if ctx.needs_input_grad[1]:
                 db = dx.sum([i for i in range(dx.ndim) if i != dim])
             return dx, db

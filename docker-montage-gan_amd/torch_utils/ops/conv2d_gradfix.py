@@ -66,7 +66,20 @@ def _pair(v):
 _conv2d_gradfix_cache = dict()
 
 
+_raw_cache = dict()
+
+
 def _conv2d_gradfix(transpose, weight_shape, stride, padding, output_padding, dilation, groups):
+    # first level: the arguments exactly as the layers pass them (ints / tuples / lists), no validation
+    raw = (transpose, tuple(weight_shape), stride if type(stride) is int else tuple(stride), padding if type(padding) is int else tuple(padding),
+           output_padding if type(output_padding) is int else tuple(output_padding), dilation if type(dilation) is int else tuple(dilation), groups)
+    cls = _raw_cache.get(raw)
+    if cls is None:
+        cls = _raw_cache[raw] = _conv2d_gradfix_build(*raw)
+    return cls
+
+
+def _conv2d_gradfix_build(transpose, weight_shape, stride, padding, output_padding, dilation, groups):
     weight_shape = tuple(weight_shape)
     stride, padding, output_padding, dilation = _pair(stride), _pair(padding), _pair(output_padding), _pair(dilation)
     key = (transpose, weight_shape, stride, padding, output_padding, dilation, groups)
@@ -103,6 +116,21 @@ def _conv2d_gradfix(transpose, weight_shape, stride, padding, output_padding, di
         def backward(ctx, grad_output):
             input, weight = ctx.saved_tensors
             grad_input = grad_weight = grad_bias = None
+            if not torch.is_grad_enabled():
+                # plain backward: both gradients from ONE aten::convolution_backward call (the same MIOpen kernels as the
+                # two differentiable ops below, without two more python autograd nodes per convolution)
+                need_w = bool(ctx.needs_input_grad[1] and not weight_gradients_disabled)
+                if ctx.needs_input_grad[0] or need_w:
+                    grad_input, grad_weight, _ = torch.ops.aten.convolution_backward(
+                        grad_output, input, weight, None, list(stride), list(padding), list(dilation), transpose,
+                        list(output_padding), groups, [bool(ctx.needs_input_grad[0]), need_w, False])
+                    if not ctx.needs_input_grad[0]:
+                        grad_input = None
+                    if not need_w:
+                        grad_weight = None
+                if ctx.needs_input_grad[2]:
+                    grad_bias = grad_output.sum([0, 2, 3])
+                return grad_input, grad_weight, grad_bias
             if ctx.needs_input_grad[0]:
                 op = _conv2d_gradfix(transpose=(not transpose), weight_shape=weight_shape,
                                      output_padding=opposite_output_padding(input.shape, grad_output.shape), **common)

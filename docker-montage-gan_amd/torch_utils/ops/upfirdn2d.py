@@ -133,6 +133,15 @@ def _upfirdn2d_ref(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
 _upfirdn2d_cuda_cache = dict()
 
 
+class _NoCtx:
+    """Stand-in for the autograd context when a Function's forward body is run outside autograd."""
+    x_shape = None
+
+    @staticmethod
+    def save_for_backward(*tensors):
+        pass
+
+
 def _upfirdn2d_cuda(up=1, down=1, padding=0, flip_filter=False, gain=1):
     """autograd.Function class for one scalar configuration (cached, reference :226-285)."""
     upx, upy = _parse_scaling(up)
@@ -170,8 +179,9 @@ def _upfirdn2d_cuda(up=1, down=1, padding=0, flip_filter=False, gain=1):
             if ctx.needs_input_grad[0]:
                 pad = [fw - px0 - 1, iw * upx - ow * downx + px0 - upx + 1,
                        fh - py0 - 1, ih * upy - oh * downy + py0 - upy + 1]
-                dx = _upfirdn2d_cuda(up=[downx, downy], down=[upx, upy], padding=pad, flip_filter=(not flip_filter),
-                                     gain=gain).apply(dy, f)
+                grad_cls = _upfirdn2d_cuda(up=[downx, downy], down=[upx, upy], padding=pad, flip_filter=(not flip_filter), gain=gain)
+                # plain backward: run the op's forward body directly; only create_graph=True needs another autograd node
+                dx = grad_cls.apply(dy, f) if torch.is_grad_enabled() else grad_cls.forward(_NoCtx, dy, f)
             assert not ctx.needs_input_grad[1], 'the FIR filter is a constant'
             return dx, None
 

@@ -17,7 +17,7 @@ import os
 import torch
 
 _stack = []
-enabled = os.environ.get('MG_WEIGHT_PREP', '1') != '0'          # module switch (tests compare both ways)
+enabled = os.environ.get('MG_WEIGHT_PREP', '1') != '0'          # module switch (MG_WEIGHT_PREP=0 turns it off; tests compare both ways)
 
 
 class _ScaleCast(torch.autograd.Function):
