@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) fma_bias_act_fwd_kernel(FbArgs<T> p)
         for (int u = 0; u < FB_U; u++) {
             const uint32_t vi = base + u * 256u + threadIdx.x;
             if (vi >= p.total_vec) continue;
-            const float dc = p.d ? p.d[plane[u]] : 1.f;
+            const float dc = p.d ? (float)to_acc<T>(from_acc<T>(p.d[plane[u]])) : 1.f;      // dcoefs.to(x.dtype), as the reference multiplies
             float bb = 0.f;
             if (p.b) { const uint32_t n = fd_div(plane[u], p.c_div); bb = to_acc<T>(p.b[plane[u] - n * p.c]); }
             V out;
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) fma_bias_act_bwd_kernel(FbArgs<T> p)
         for (int u = 0; u < FB_U; u++) {
             const uint32_t vi = base + u * 256u + threadIdx.x;
             if (vi >= p.total_vec) continue;
-            const float dc = p.d ? p.d[fd_div(vi, p.hwv_div)] : 1.f;
+            const float dc = p.d ? (float)to_acc<T>(from_acc<T>(p.d[fd_div(vi, p.hwv_div)])) : 1.f;
             V o1, o2;
             #pragma unroll
             for (int e = 0; e < VEC; e++) {
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) bwd_fused_kernel(BrArgs<T> p)
     const uint32_t n = plane / p.c, ch = plane - n * p.c;
     const size_t base = (size_t)plane * p.hw;
     const uint32_t lo = slice * p.slice_len, hi = min(p.hw, lo + p.slice_len);
-    const float dc = p.d ? p.d[plane] : 1.f;
+    const float dc = p.d ? (float)to_acc<T>(from_acc<T>(p.d[plane])) : 1.f;        // dcoefs.to(x.dtype)
     const float* nz = p.noise ? p.noise + (int64_t)n * p.noise_stride_n : nullptr;
     typedef float f4_t __attribute__((ext_vector_type(4)));
     const bool nz_vec = (VEC == 1) || ((((uintptr_t)p.noise) & 15) == 0 && ((p.noise_stride_n * 4) & 15) == 0);
@@ -391,6 +391,8 @@ __global__ void __launch_bounds__(256) fma_bias_act_nhwc_fwd_kernel(FnArgs<T> p)
                     const f4_t t = dp[q];
                     dv[u][4 * q] = t.x; dv[u][4 * q + 1] = t.y; dv[u][4 * q + 2] = t.z; dv[u][4 * q + 3] = t.w;
                 }
+                #pragma unroll
+                for (int e = 0; e < VEC; e++) dv[u][e] = to_acc<T>(from_acc<T>(dv[u][e]));       // dcoefs.to(x.dtype)
             }
         }
         #pragma unroll
@@ -439,6 +441,8 @@ __global__ void __launch_bounds__(256) bwd_fused_nhwc_kernel(BnArgs<T> p)
         const f4_t* dp = (const f4_t*)(p.d + (size_t)n * p.c + cvi * VEC);
         #pragma unroll
         for (int q = 0; q < VEC / 4; q++) { const f4_t t = dp[q]; dv[4 * q] = t.x; dv[4 * q + 1] = t.y; dv[4 * q + 2] = t.z; dv[4 * q + 3] = t.w; }
+        #pragma unroll
+        for (int e = 0; e < VEC; e++) dv[e] = to_acc<T>(from_acc<T>(dv[e]));                      // dcoefs.to(x.dtype)
     }
     float s_gd[VEC], s_gb[VEC], s_gs = 0.f;
     #pragma unroll

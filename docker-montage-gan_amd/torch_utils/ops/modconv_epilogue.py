@@ -73,8 +73,8 @@ def _epilogue_hip(act, alpha, gain, clamp):
             nhwc = _is_nhwc(x)
             if not nhwc:
                 x = x.contiguous()
-            # the reference multiplies by dcoefs.to(x.dtype): keep that rounding, then widen for the kernel
-            d32 = dcoefs.detach().to(x.dtype).to(torch.float32).contiguous() if dcoefs is not None else None
+            # the reference multiplies by dcoefs.to(x.dtype): the kernel applies that rounding to the float32 values it is handed
+            d32 = dcoefs.detach().to(torch.float32).contiguous() if dcoefs is not None else None       # rounded to x.dtype inside the kernel
             nz32, nz_stride, s32 = None, 0, None
             if noise is not None:
                 assert noise.numel() in (h * w, n * h * w), 'noise must be [H,W] or [N,1,H,W]'
@@ -136,7 +136,7 @@ def _epilogue_hip(act, alpha, gain, clamp):
             acc = torch.zeros([n * c + nb + native.GS_SLOTS], dtype=torch.float32, device=x.device)
             gd_a, gb_a, gs_a = acc[:n * c], acc[n * c:n * c + nb], acc[n * c + nb:]     # gs: GS_SLOTS partial sums
             stride = ctx.noise_meta[2] if has_nz else 0
-            d32 = dcoefs.to(x.dtype).to(torch.float32).contiguous() if has_d else None
+            d32 = dcoefs.to(torch.float32).contiguous() if has_d else None
             if x.numel():
                 with native.guard(x.device):
                     bwd = native.lib().mg_bwd_fused_nhwc if nhwc else native.lib().mg_bwd_fused
@@ -187,7 +187,7 @@ class _ChannelScale(torch.autograd.Function):
         nhwc = _is_nhwc(x)
         if not nhwc:
             x = x.contiguous()
-        s32 = s.detach().to(x.dtype).to(torch.float32).contiguous()      # styles.to(x.dtype), as the reference
+        s32 = s.detach().to(torch.float32).contiguous()      # the kernel rounds it to x.dtype (styles.to(x.dtype), as the reference)
         y = torch.empty_like(x)
         ctx.nhwc = nhwc
         if x.numel():
@@ -211,7 +211,7 @@ class _ChannelScale(torch.autograd.Function):
         dx = torch.empty_like(x)
         want_ds = ctx.needs_input_grad[1]
         gd = torch.zeros([n * c], dtype=torch.float32, device=x.device) if want_ds else None
-        s32 = s.to(x.dtype).to(torch.float32).contiguous()
+        s32 = s.to(torch.float32).contiguous()
         if x.numel():
             with native.guard(x.device):
                 bwd = native.lib().mg_bwd_fused_nhwc if ctx.nhwc else native.lib().mg_bwd_fused

@@ -12,6 +12,7 @@ either way, so the first step costs kernel compilation only.  With ``cudnn.bench
 setting, training_loop.py:124) pass ``find_mode='FAST'`` for the same behaviour through MIOpen's find API.
 It must run before the first convolution of the process.
 """
+import atexit
 import os
 import shutil
 import tempfile
@@ -30,6 +31,7 @@ def use_tuned_miopen_db(find_mode=None):
         return None
     # a private, writable copy per process: MIOpen locks and may append to its user databases
     dst = tempfile.mkdtemp(prefix='montage_miopen_db_')
+    atexit.register(shutil.rmtree, dst, ignore_errors=True)
     for f in files:
         shutil.copy(os.path.join(DB_DIR, f), os.path.join(dst, f))
     os.environ['MIOPEN_USER_DB_PATH'] = dst

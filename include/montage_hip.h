@@ -126,7 +126,8 @@ int mg_bias_act(const void* x, const void* b, const void* xref, const void* yref
  * contiguous; d (float32 [N,C]), noise (float32, sample n at noise + n*noise_stride_n:
  * stride 0 = one [H*W] map shared by the batch, H*W = per-sample maps) and b may each be NULL;
  * the noise multiplier is noise_gain * (noise_gain_dev ? *noise_gain_dev : 1) -- a DEVICE scalar, so the
- * learned noise_strength never has to be read back by the host.
+ * learned noise_strength never has to be read back by the host.  d is rounded to the tensor dtype inside the
+ * kernels (the reference multiplies by dcoefs.to(x.dtype)), so callers hand over the float32 values as they are.
  * One read and one write of x instead of the three round trips of
  * fma.fma + bias_act.bias_act (training/networks.py:86-88, 311-313).
  * mg_fma_bias_act_bwd: dx_pre = dy * act'(yref) * gain masked by the clamp
