@@ -321,11 +321,60 @@ __global__ void __launch_bounds__(256) bwd_fused_kernel(BrArgs<T> p)
     }
 }
 
+// Small planes (the 16x16 ... 4x4 float32 blocks: 16 k planes of 256 / 64 / 16 elements): one WAVE per plane, four
+// planes per workgroup, wave-shuffle reductions only -- no LDS, no barrier, and four times fewer workgroups than
+// the plane-per-workgroup kernel above, which leaves 3/4 (or more) of its lanes idle on such planes.
+template <class T, int A, int VEC>
+__global__ void __launch_bounds__(256) bwd_fused_small_kernel(BrArgs<T> p, uint32_t planes)
+{
+    struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
+    const BaConst<float> k = {p.alpha, p.gain, p.clamp};
+    const uint32_t lane = threadIdx.x & 63, plane = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (plane >= planes) return;                                    // wave-uniform
+    const uint32_t n = plane / p.c, ch = plane - n * p.c;
+    const size_t base = (size_t)plane * p.hw;
+    const float dc = p.d ? (float)to_acc<T>(from_acc<T>(p.d[plane])) : 1.f;
+    const float* nz = p.noise ? p.noise + (int64_t)n * p.noise_stride_n : nullptr;
+    float s_gd = 0.f, s_gb = 0.f, s_gs = 0.f;
+    for (uint32_t i = lane * VEC; i < p.hw; i += 64u * VEC) {
+        const V vdy = *(const V*)(p.dy + base + i);
+        V vy, vx, out;
+        if (p.yref) vy = *(const V*)(p.yref + base + i);
+        if (p.x) vx = *(const V*)(p.x + base + i);
+        #pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            float g = to_acc<T>(vdy.v[e]);
+            if (p.yref) g = ba_eval<float, A>(1, g, 0.f, 0.f, to_acc<T>(vy.v[e]), 1.f, k);
+            const float gq = to_acc<T>(from_acc<T>(g));
+            out.v[e] = from_acc<T>(gq * dc);
+            s_gb += gq;
+            if (p.x) s_gd += gq * to_acc<T>(vx.v[e]);
+            if (nz) s_gs += gq * nz[i + e];
+        }
+        *(V*)(p.dx + base + i) = out;
+    }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s_gd += __shfl_down(s_gd, o, 64); s_gb += __shfl_down(s_gb, o, 64); s_gs += __shfl_down(s_gs, o, 64);
+    }
+    if (lane == 0) {
+        if (p.gd) atomicAdd(p.gd + plane, s_gd);
+        if (p.gb) atomicAdd(p.gb + ch, s_gb);
+        if (p.gs) atomicAdd(p.gs + (blockIdx.x % MG_GS_SLOTS), s_gs);
+    }
+}
+
 template <class T, int A>
 void launch_br(BrArgs<T> p, bool wide, uint32_t planes, hipStream_t s)
 {
     constexpr int VEC = 16 / sizeof(T);
     const uint32_t vec = wide ? VEC : 1;
+    if (p.hw <= 64u * vec * 4u && planes >= 1024u) {                // small planes, many of them: one wave per plane
+        const uint32_t blocks = (planes + 3u) / 4u;
+        if (wide) hipLaunchKernelGGL((bwd_fused_small_kernel<T, A, VEC>), dim3(blocks), dim3(256), 0, s, p, planes);
+        else      hipLaunchKernelGGL((bwd_fused_small_kernel<T, A, 1>), dim3(blocks), dim3(256), 0, s, p, planes);
+        return;
+    }
     const uint32_t unit = 256u * vec;
     uint32_t slices = (p.hw + unit * 8 - 1) / (unit * 8);          // about 8 vectors per lane per slice (2 rounds of 4 in flight)
     if (slices < 1) slices = 1;
