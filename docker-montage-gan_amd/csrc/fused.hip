@@ -1,6 +1,6 @@
 // fused.hip -- fusions the plugin API permits without changing what callers compute.
 //
-//  * mg_fma_bias_act / _bwd: the modulated-conv epilogue of SynthesisLayer,
+//  * mg_fma_bias_act (backward: mg_bwd_fused below): the modulated-conv epilogue of SynthesisLayer,
 //      x = fma(x, dcoefs[N,C,1,1], noise[1,1,H,W]) ; x = bias_act(x, b, act, gain, clamp)
 //    (reference training/networks.py:86-88 + 311-313 -> fma.py:16, bias_act.py:71)
 //    as ONE read and ONE write of the activation instead of three round trips.
@@ -81,42 +81,8 @@ __global__ void __launch_bounds__(256) fma_bias_act_fwd_kernel(FbArgs<T> p)
     }
 }
 
-// backward.  x := dy, b := yref here.  y = dx = dpre * d[plane], y2 = dpre (optional).
-template <class T, int A, int VEC>
-__global__ void __launch_bounds__(256) fma_bias_act_bwd_kernel(FbArgs<T> p)
-{
-    struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
-    const BaConst<float> k = {p.alpha, p.gain, p.clamp};
-    for (uint32_t base = blockIdx.x * (256u * FB_U); base < p.total_vec; base += gridDim.x * (256u * FB_U)) {
-        V dy[FB_U], yr[FB_U];
-        #pragma unroll
-        for (int u = 0; u < FB_U; u++) {
-            const uint32_t vi = base + u * 256u + threadIdx.x;
-            if (vi >= p.total_vec) continue;
-            dy[u] = ((const V*)p.x)[vi];
-            yr[u] = ((const V*)p.b)[vi];
-        }
-        #pragma unroll
-        for (int u = 0; u < FB_U; u++) {
-            const uint32_t vi = base + u * 256u + threadIdx.x;
-            if (vi >= p.total_vec) continue;
-            const float dc = p.d ? (float)to_acc<T>(from_acc<T>(p.d[fd_div(vi, p.hwv_div)])) : 1.f;
-            V o1, o2;
-            #pragma unroll
-            for (int e = 0; e < VEC; e++) {
-                float g = ba_eval<float, A>(1, to_acc<T>(dy[u].v[e]), 0.f, 0.f, to_acc<T>(yr[u].v[e]), 1.f, k);
-                o2.v[e] = from_acc<T>(g);
-                // dx is the gradient through fma of the T-rounded bias_act gradient
-                o1.v[e] = from_acc<T>(to_acc<T>(o2.v[e]) * dc);
-            }
-            ((V*)p.y)[vi] = o1;
-            if (p.y2) ((V*)p.y2)[vi] = o2;
-        }
-    }
-}
-
 template <class T, int A>
-void launch_fb(const FbArgs<T>& p0, bool bwd, bool wide, hipStream_t s)
+void launch_fb(const FbArgs<T>& p0, bool wide, hipStream_t s)
 {
     constexpr int VEC = 16 / sizeof(T);
     FbArgs<T> p = p0;
@@ -126,27 +92,22 @@ void launch_fb(const FbArgs<T>& p0, bool bwd, bool wide, hipStream_t s)
     uint32_t blocks = (p.total_vec + 256u * FB_U - 1) / (256u * FB_U);
     if (blocks > 256u * 8u) blocks = 256u * 8u;
     if (blocks < 1) blocks = 1;
-    if (!bwd) {
-        if (wide) hipLaunchKernelGGL((fma_bias_act_fwd_kernel<T, A, VEC>), dim3(blocks), dim3(256), 0, s, p);
-        else      hipLaunchKernelGGL((fma_bias_act_fwd_kernel<T, A, 1>), dim3(blocks), dim3(256), 0, s, p);
-    } else {
-        if (wide) hipLaunchKernelGGL((fma_bias_act_bwd_kernel<T, A, VEC>), dim3(blocks), dim3(256), 0, s, p);
-        else      hipLaunchKernelGGL((fma_bias_act_bwd_kernel<T, A, 1>), dim3(blocks), dim3(256), 0, s, p);
-    }
+    if (wide) hipLaunchKernelGGL((fma_bias_act_fwd_kernel<T, A, VEC>), dim3(blocks), dim3(256), 0, s, p);
+    else      hipLaunchKernelGGL((fma_bias_act_fwd_kernel<T, A, 1>), dim3(blocks), dim3(256), 0, s, p);
 }
 
 template <class T>
-int dispatch_fb(const FbArgs<T>& p, int act, bool bwd, bool wide, hipStream_t s)
+int dispatch_fb(const FbArgs<T>& p, int act, bool wide, hipStream_t s)
 {
     switch (act) {
-    case 1: launch_fb<T, 1>(p, bwd, wide, s); return MG_OK;
-    case 2: launch_fb<T, 2>(p, bwd, wide, s); return MG_OK;
-    case 3: launch_fb<T, 3>(p, bwd, wide, s); return MG_OK;
-    case 4: launch_fb<T, 4>(p, bwd, wide, s); return MG_OK;
-    case 5: launch_fb<T, 5>(p, bwd, wide, s); return MG_OK;
-    case 6: launch_fb<T, 6>(p, bwd, wide, s); return MG_OK;
-    case 7: launch_fb<T, 7>(p, bwd, wide, s); return MG_OK;
-    case 8: launch_fb<T, 8>(p, bwd, wide, s); return MG_OK;
+    case 1: launch_fb<T, 1>(p, wide, s); return MG_OK;
+    case 2: launch_fb<T, 2>(p, wide, s); return MG_OK;
+    case 3: launch_fb<T, 3>(p, wide, s); return MG_OK;
+    case 4: launch_fb<T, 4>(p, wide, s); return MG_OK;
+    case 5: launch_fb<T, 5>(p, wide, s); return MG_OK;
+    case 6: launch_fb<T, 6>(p, wide, s); return MG_OK;
+    case 7: launch_fb<T, 7>(p, wide, s); return MG_OK;
+    case 8: launch_fb<T, 8>(p, wide, s); return MG_OK;
     }
     mg_set_error("fma_bias_act: activation %d needs the pre-activation input and is not fusable", act);
     return MG_E_ARG;
@@ -612,37 +573,10 @@ extern "C" int mg_fma_bias_act(const void* x, const float* d, const float* noise
         p.x = (const T*)x; p.d = d; p.noise = noise; p.b = (const T*)b; p.y = (T*)y; p.y2 = nullptr;
         p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_gain = noise_gain; p.noise_gain_dev = noise_gain_dev; p.noise_stride_n = noise_stride_n;
         p.c = (uint32_t)c; p.hw = (uint32_t)hw; p.total_vec = (uint32_t)total; p.c_div = make_fastdiv((uint32_t)c);
-        rc = dispatch_fb<T>(p, act, false, wide, s);
+        rc = dispatch_fb<T>(p, act, wide, s);
     });
     if (rc) return rc;
     return mg_check_launch(MG_K_FMA_BIAS_ACT, "fma_bias_act");
-}
-
-extern "C" int mg_fma_bias_act_bwd(const void* dy, const void* yref, const float* d, void* dx, void* dpre, int dtype,
-                                   int act, float alpha, float gain, float clamp, int32_t n, int32_t c, int32_t hw,
-                                   void* stream)
-{
-    MG_REQUIRE(dy && yref && dx, "dy must reside on the device");
-    MG_REQUIRE(dtype == MG_F32 || dtype == MG_F16 || dtype == MG_BF16, "fma_bias_act: unsupported dtype %d", dtype);
-    MG_REQUIRE(n >= 0 && c >= 1 && hw >= 1, "fma_bias_act: bad shape");
-    int64_t total = (int64_t)n * c * hw;
-    MG_REQUIRE(total <= INT32_MAX, "x is too large");
-    if (total == 0) return MG_OK;
-    int es = mg_dtype_size(dtype), vec = 16 / es;
-    bool wide = (hw % vec == 0) && ((((uintptr_t)dy | (uintptr_t)yref | (uintptr_t)dx | (uintptr_t)dpre) & 15) == 0);
-    hipStream_t s = (hipStream_t)stream;
-    MgLaunchScope scope(MG_K_FMA_BIAS_ACT, s, (3.0 + (dpre != nullptr)) * total * es);
-    int rc = MG_OK;
-    MG_DISPATCH_DTYPE(dtype, {
-        if (sizeof(T) == 8) break;
-        FbArgs<T> p;
-        p.x = (const T*)dy; p.d = d; p.noise = nullptr; p.b = (const T*)yref; p.y = (T*)dx; p.y2 = (T*)dpre;
-        p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_gain = 0.f; p.noise_gain_dev = nullptr; p.noise_stride_n = 0;
-        p.c = (uint32_t)c; p.hw = (uint32_t)hw; p.total_vec = (uint32_t)total; p.c_div = make_fastdiv((uint32_t)c);
-        rc = dispatch_fb<T>(p, act, true, wide, s);
-    });
-    if (rc) return rc;
-    return mg_check_launch(MG_K_FMA_BIAS_ACT, "fma_bias_act_bwd");
 }
 
 extern "C" int mg_filtered_lrelu(const void* x, const void* b, const float* fu, const float* fd, void* y, int dtype,

@@ -55,8 +55,6 @@ def _declare(L):
                               c_float, c_float, c_float, c_i64, c_i32, c_i64, c_void_p]
     L.mg_fma_bias_act.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
                                   c_float, c_float, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p]
-    L.mg_fma_bias_act_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
-                                      c_float, c_i32, c_i32, c_i32, c_void_p]
     L.mg_bwd_fused.argtypes = [c_void_p] * 9 + [c_int, c_int, c_float, c_float, c_float, c_i64, c_i32, c_i32, c_i32, c_void_p]
     L.mg_fma_bias_act_nhwc.argtypes = L.mg_fma_bias_act.argtypes
     L.mg_affine_warp_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p]
@@ -71,7 +69,7 @@ def _declare(L):
                                                 c_float, c_void_p]
     L.mg_filtered_lrelu.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_i32] * 10 + \
                                    [c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p]
-    for name in ('mg_upfirdn2d', 'mg_upfirdn2d_index_table', 'mg_bias_act', 'mg_fma_bias_act', 'mg_fma_bias_act_bwd',
+    for name in ('mg_upfirdn2d', 'mg_upfirdn2d_index_table', 'mg_bias_act', 'mg_fma_bias_act',
                  'mg_alpha_composite_fwd', 'mg_alpha_composite_bwd', 'mg_translate_sample_fwd',
                  'mg_translate_sample_bwd_input', 'mg_translate_sample_bwd_shift', 'mg_filtered_lrelu', 'mg_bwd_fused',
                  'mg_fma_bias_act_nhwc', 'mg_bwd_fused_nhwc', 'mg_affine_warp_fwd', 'mg_affine_warp_bwd', 'mg_channel_mix',

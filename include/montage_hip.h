@@ -130,17 +130,12 @@ int mg_bias_act(const void* x, const void* b, const void* xref, const void* yref
  * kernels (the reference multiplies by dcoefs.to(x.dtype)), so callers hand over the float32 values as they are.
  * One read and one write of x instead of the three round trips of
  * fma.fma + bias_act.bias_act (training/networks.py:86-88, 311-313).
- * mg_fma_bias_act_bwd: dx_pre = dy * act'(yref) * gain masked by the clamp
- * (this is d/d(pre-activation)); dx = dx_pre * d[n,c]; writes dx and, when
- * `dpre` is non NULL, dx_pre itself (needed for d(d), d(noise), d(b) sums).    */
+ * The backward pass is mg_bwd_fused (below): dx and all three reductions in one pass.    */
 int mg_fma_bias_act(const void* x, const float* d, const float* noise, const void* b,
                     void* y, int dtype, int act, float alpha, float gain, float clamp,
                     float noise_gain, const float* noise_gain_dev, int64_t noise_stride_n,
                     int32_t n, int32_t c, int32_t hw, void* stream);
-int mg_fma_bias_act_bwd(const void* dy, const void* yref, const float* d,
-                        void* dx, void* dpre, int dtype, int act, float alpha,
-                        float gain, float clamp, int32_t n, int32_t c, int32_t hw,
-                        void* stream);
+
 
 /* ---- fused backward with reductions -----------------------------------------
  * One pass for what autograd otherwise does in up to five: NCHW contiguous, planes (n,c) of hw elements.
