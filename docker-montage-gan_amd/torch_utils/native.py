@@ -50,6 +50,7 @@ def _declare(L):
                                   ctypes.POINTER(ctypes.c_double)]
     L.mg_upfirdn2d.argtypes = [c_void_p, c_void_p, c_void_p, c_int, I32x4, I64x4, I32x2, I64x2, I32x4, I64x4,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]
+    L.mg_upfirdn2d_sep.argtypes = [c_void_p, c_void_p, c_void_p, c_int] + [c_i32] * 7 + [c_int] * 7 + [c_float, c_void_p]
     L.mg_upfirdn2d_index_table.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     L.mg_bias_act.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                               c_float, c_float, c_float, c_i64, c_i32, c_i64, c_void_p]
@@ -69,7 +70,7 @@ def _declare(L):
                                                 c_float, c_void_p]
     L.mg_filtered_lrelu.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_i32] * 10 + \
                                    [c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p]
-    for name in ('mg_upfirdn2d', 'mg_upfirdn2d_index_table', 'mg_bias_act', 'mg_fma_bias_act',
+    for name in ('mg_upfirdn2d', 'mg_upfirdn2d_sep', 'mg_upfirdn2d_index_table', 'mg_bias_act', 'mg_fma_bias_act',
                  'mg_alpha_composite_fwd', 'mg_alpha_composite_bwd', 'mg_translate_sample_fwd',
                  'mg_translate_sample_bwd_input', 'mg_translate_sample_bwd_shift', 'mg_filtered_lrelu', 'mg_bwd_fused',
                  'mg_fma_bias_act_nhwc', 'mg_bwd_fused_nhwc', 'mg_affine_warp_fwd', 'mg_affine_warp_bwd', 'mg_channel_mix',

@@ -105,6 +105,15 @@ int mg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
  * coordinate o in [0, out_size) writes {in0, count, filter0} as computed on the
  * DEVICE by the same code the kernels use (upfirdn2d.cu:43-48, 60-65).
  * `table` is device memory, int32[out_size*3].                                */
+/* Separable filter on both axes in one launch: the two calls the reference's op makes for a 1-D filter
+ * (upfirdn2d.py:253-257: f[None,:] along x, then f[:,None] along y, gain sqrt(gain) each) with the intermediate
+ * kept in LDS.  x, y dense NCHW; f float32 [fsize <= 12]; up / down in {1,2} per axis; out sizes as for the two
+ * calls; gain_pass = sqrt(gain).  Values are identical to the two-launch composition (same tap order, the
+ * intermediate rounded to the tensor dtype).                                                               */
+int mg_upfirdn2d_sep(const void* x, const float* f, void* y, int dtype, int32_t n, int32_t c, int32_t in_h, int32_t in_w,
+                     int32_t out_h, int32_t out_w, int32_t fsize, int upx, int upy, int downx, int downy,
+                     int padx0, int pady0, int flip, float gain_pass, void* stream);
+
 int mg_upfirdn2d_index_table(int32_t* table, int out_size, int in_size,
                              int up, int down, int pad0, int filter_size,
                              int flip, void* stream);

@@ -49,7 +49,8 @@ def close_lowp(got, want, dtype, what=''):
 def test_upfirdn2d_golden_fwd_bwd(native):
     U = op('upfirdn2d')
     cases, arr = load_golden('upfirdn2d')
-    before = native.launch_count(native.K_UPFIRDN2D_GENERIC) + native.launch_count(native.K_UPFIRDN2D_TILED) + native.launch_count(native.K_UPFIRDN2D_STREAM)
+    kinds = (native.K_UPFIRDN2D_GENERIC, native.K_UPFIRDN2D_TILED, native.K_UPFIRDN2D_STREAM, native.K_UPFIRDN2D_NHWC)
+    before = sum(native.launch_count(k) for k in kinds)
     for c in cases:
         i = c['id']
         y, dx = run_upfirdn2d_case(U, c, arr, device=DEV, impl='cuda')
@@ -58,8 +59,8 @@ def test_upfirdn2d_golden_fwd_bwd(native):
             assert y.is_contiguous(memory_format=torch.channels_last), c      # suggest_memory_format (upfirdn2d.cpp:35)
         np.testing.assert_allclose(y.detach().cpu().numpy(), arr[f'c{i}_y'], rtol=1e-4, atol=1e-5, err_msg=str(c))
         np.testing.assert_allclose(dx.cpu().numpy(), arr[f'c{i}_dx'], rtol=1e-4, atol=1e-5, err_msg=str(c))
-    after = native.launch_count(native.K_UPFIRDN2D_GENERIC) + native.launch_count(native.K_UPFIRDN2D_TILED) + native.launch_count(native.K_UPFIRDN2D_STREAM)
-    assert after - before >= 2 * len(cases), 'the native kernels did not run'
+    after = sum(native.launch_count(k) for k in kinds)
+    assert after - before >= 2 * len(cases), 'the native kernels did not run'      # >= one forward and one backward launch per case
 
 
 def test_upfirdn2d_index_table_bit_exact(native, oracle):
@@ -245,6 +246,47 @@ def test_channels_last_epilogue_and_backward_match_nchw(native, dtype):
             res.append((y.detach(), gx, gb))
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), 'bias_act nhwc'
         close_lowp(res[1][2].float().cpu().numpy(), res[0][2].float().cpu().numpy(), dtype, 'bias_act db')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+def test_upfirdn2d_separable_one_launch_equals_two_launches(native, oracle, dtype):
+    """1-D filters: the reference's op runs a row pass and a column pass (upfirdn2d.py:253-257).  mg_upfirdn2d_sep does
+    both in one launch with the intermediate in LDS; values and input gradients must be IDENTICAL to the two-launch
+    composition (same tap order, intermediate rounded to the tensor dtype), and the composition is pinned to the
+    oracle here once more.  Covers ADA's four resampling passes (12-tap sym6, up 2 / down 2, negative padding,
+    flipped filter), odd sizes and tile boundaries."""
+    U = op('upfirdn2d')
+    rng = np.random.RandomState(12)
+    f12 = T(np.asarray([0.0154, 0.0035, -0.118, -0.0483, 0.4911, 0.7876, 0.3379, -0.0726, -0.0211, 0.0447, 0.0018, -0.0078], dtype=np.float32))
+    f5 = T(np.asarray([1, 4, 6, 4, 1], dtype=np.float32) / 16)
+    cases = [
+        (U.upsample2d, dict(f=f12, up=2), [3, 4, 37, 41]),
+        (U.downsample2d, dict(f=f12, down=2, padding=-6, flip_filter=True), [2, 4, 100, 90]),
+        (U.downsample2d, dict(f=f12, down=2), [2, 3, 33, 130]),
+        (U.filter2d, dict(f=f12, gain=2.0), [2, 2, 20, 70]),
+        (U.filter2d, dict(f=f5, flip_filter=True), [1, 5, 17, 65]),
+        (U.upsample2d, dict(f=f5, up=2, padding=[1, 0, 2, -1]), [2, 2, 16, 16]),
+        (U.upfirdn2d, dict(f=f12, up=[2, 1], down=[1, 2], padding=[3, 2, 5, 4]), [1, 3, 40, 24]),
+    ]
+    try:
+        for fn, kw, shape in cases:
+            x0 = T(rng.randn(*shape).astype(np.float32)).to(dtype).to(DEV)
+            kw = dict(kw, f=kw['f'].to(DEV))
+            res = []
+            for one in (True, False):
+                U.sep_one_launch = one
+                x = x0.clone().requires_grad_(True)
+                y = fn(x, **kw)
+                gy = torch.ones_like(y) * torch.linspace(-1, 1, y.shape[-1], device=DEV).to(dtype)
+                gx, = torch.autograd.grad([y], [x], [gy])
+                res.append((y.detach(), gx))
+            assert torch.equal(res[0][0], res[1][0]), (fn.__name__, shape, dtype)
+            assert torch.equal(res[0][1], res[1][1]), ('grad', fn.__name__, shape, dtype)
+            if fn is U.upsample2d and kw['f'].numel() == 12 and dtype == torch.float32:
+                want = oracle.upfirdn2d_api(x0.float().cpu().numpy(), np.outer(f12.numpy(), f12.numpy()), up=2, padding=[6, 5, 6, 5], gain=4)
+                np.testing.assert_allclose(res[0][0].float().cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+    finally:
+        U.sep_one_launch = True
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16, torch.float64])
