@@ -182,10 +182,36 @@ __global__ void __launch_bounds__(256) upfirdn2d_tiled(UfParams p, int tiles_x, 
     for (int j = 0; j < MY; j++) {
         int oy = out_y0 + ty * MY + j;
         if (oy >= p.out_h) continue;
+        T* rowp = yp + (int64_t)oy * p.out_w + out_x0 + tx * MX;
+        if constexpr (MX == 4 || MX == 2) {
+            // the lane's MX outputs are adjacent: one aligned vector store (16 / 8 / 4 bytes) instead of MX scalar ones
+            // whose lanes sit 4*MX bytes apart (a quarter of each write transaction used)
+            if (out_x0 + tx * MX + MX - 1 < p.out_w) {
+                T vals[MX];
+                #pragma unroll
+                for (int i = 0; i < MX; i++) vals[i] = from_acc<T>(acc[j][i] * p.gain);
+                const uintptr_t a = (uintptr_t)rowp;
+                if ((a & (sizeof(T) * MX - 1)) == 0) {
+                    struct alignas(sizeof(T) * MX) VS { T v[MX]; };
+                    VS o;
+                    #pragma unroll
+                    for (int i = 0; i < MX; i++) o.v[i] = vals[i];
+                    *(VS*)rowp = o;
+                    continue;
+                }
+                if (MX == 4 && (a & (sizeof(T) * 2 - 1)) == 0) {
+                    struct alignas(sizeof(T) * 2) V2 { T v[2]; };
+                    V2 lo, hi;
+                    lo.v[0] = vals[0]; lo.v[1] = vals[1]; hi.v[0] = vals[MX - 2]; hi.v[1] = vals[MX - 1];
+                    ((V2*)rowp)[0] = lo; ((V2*)rowp)[1] = hi;
+                    continue;
+                }
+            }
+        }
         #pragma unroll
         for (int i = 0; i < MX; i++) {
             int ox = out_x0 + tx * MX + i;
-            if (ox < p.out_w) yp[(int64_t)oy * p.out_w + ox] = from_acc<T>(acc[j][i] * p.gain);
+            if (ox < p.out_w) rowp[i] = from_acc<T>(acc[j][i] * p.gain);
         }
     }
 }
