@@ -91,10 +91,16 @@ struct TileGeom {
     static constexpr int TW = TXT * MX, TH = TYT * MY;                        // output tile
     static constexpr int TIW = (PX + (TW - 1) * DNX + FW - 1) / UPX + 1;     // input footprint
     static constexpr int TIH = (PY + (TH - 1) * DNY + FH - 1) / UPY + 1;
-    static constexpr int LDW = TIW | 1;                                       // odd row pitch: no bank conflicts
     static constexpr int RX = (PX + (MX - 1) * DNX + FW - 1) / UPX + 1;      // per-lane register window
     static constexpr int RY = (PY + (MY - 1) * DNY + FH - 1) / UPY + 1;
     static constexpr int LANE_DX = MX * DNX / UPX, LANE_DY = MY * DNY / UPY;  // window origin step per lane
+    // LDS row layout: neighbouring lanes read columns LANE_DX apart, which would be a LANE_DX-way bank conflict in a
+    // plain row.  Columns are de-interleaved by LD = LANE_DX: column c lives at (c % LD) * KP + c / LD, so that for a
+    // fixed window offset the lanes of a row hit consecutive words; KP odd keeps the staging writes conflict free too.
+    static constexpr int LD = LANE_DX < 1 ? 1 : LANE_DX;
+    static constexpr int KP = ((TIW + LD - 1) / LD) | 1;
+    static constexpr int LDW = LD * KP;
+    static constexpr int col(int c) { return (c % LD) * KP + c / LD; }
     static_assert((MX * DNX) % UPX == 0 && (MY * DNY) % UPY == 0, "micro tile must span whole input samples");
     static_assert((TW * DNX) % UPX == 0 && (TH * DNY) % UPY == 0, "tile phase must repeat");
 };
@@ -136,7 +142,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_tiled(UfParams p, int tiles_x, 
         float v = 0.f;
         if (ix >= 0 && iy >= 0 && ix < p.in_w && iy < p.in_h && plane < planes)
             v = (float)to_acc<T>(((const T*)p.x)[(int64_t)plane * p.in_h * p.in_w + (int64_t)iy * p.in_w + ix]);
-        sx[pz][ry][rx] = v;
+        sx[pz][ry][G::col(rx)] = v;
     }
     __syncthreads();
 
@@ -155,7 +161,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_tiled(UfParams p, int tiles_x, 
     for (int ry = 0; ry < G::RY; ry++) {
         float row[G::RX];
         #pragma unroll
-        for (int rx = 0; rx < G::RX; rx++) row[rx] = sx[pz][ty * G::LANE_DY + ry][tx * G::LANE_DX + rx];
+        for (int rx = 0; rx < G::RX; rx++) row[rx] = sx[pz][ty * G::LANE_DY + ry][(rx % G::LD) * G::KP + tx + rx / G::LD];   // = col(tx * LANE_DX + rx)
         #pragma unroll
         for (int j = 0; j < MY; j++) {
             // up-sampled position of output j's first tap relative to the lane window
