@@ -499,6 +499,26 @@ template <class T> __device__ __forceinline__ u32x4_t nhwc_pack(const float (&v)
     return r;
 }
 
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+// Pairs of adjacent channels share every tap, so the MACs are issued as packed v_pk_fma_f32 (two IEEE fmas per lane
+// per instruction -- same results, half the VALU issue slots; the 4x4 FIR is VALU-bound at 16 MACs per output).
+template <class T> __device__ __forceinline__ void nhwc_unpack2(const u32x4_t& r, f2_t (&v)[NhwcVec<T>::VEC / 2])
+{
+    float t[NhwcVec<T>::VEC];
+    nhwc_unpack<T>(r, t);
+    #pragma unroll
+    for (int h = 0; h < NhwcVec<T>::VEC / 2; h++) v[h] = (f2_t){t[2 * h], t[2 * h + 1]};
+}
+
+template <class T> __device__ __forceinline__ u32x4_t nhwc_pack2(const f2_t (&v)[NhwcVec<T>::VEC / 2])
+{
+    float t[NhwcVec<T>::VEC];
+    #pragma unroll
+    for (int h = 0; h < NhwcVec<T>::VEC / 2; h++) { t[2 * h] = v[h].x; t[2 * h + 1] = v[h].y; }
+    return nhwc_pack<T>(t);
+}
+
 struct NhwcGrid { uint32_t cv, gx, nchunks, total, rows_per_chunk; FastDiv cv_div, gx_div, chunk_div; };
 
 template <class T, int UP, int DN, int PX, int PY, int MX, int MY>
@@ -550,13 +570,13 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
 
     for (int oy0 = oy_begin; oy0 < oy_end; oy0 += MY) {
         const int iy0 = iy_base + oy0 / MY * LANE_DY;
-        float acc[MY][MX][VEC];
+        f2_t acc[MY][MX][VEC / 2];
         #pragma unroll
         for (int j = 0; j < MY; j++)
             #pragma unroll
             for (int i = 0; i < MX; i++)
                 #pragma unroll
-                for (int e = 0; e < VEC; e++) acc[j][i][e] = 0.f;
+                for (int e = 0; e < VEC / 2; e++) acc[j][i][e] = (f2_t){0.f, 0.f};
 
         // rows are requested RG at a time (at most 16 vectors = 64 VGPRs in flight), then consumed
         constexpr int RG = (RX * RY <= 16) ? RY : (16 / RX);
@@ -580,9 +600,9 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
             for (int r = 0; r < RG; r++) {
                 const int ry = ry0 + r;
                 if (ry >= RY) break;
-                float row[RX][VEC];
+                f2_t row[RX][VEC / 2];
                 #pragma unroll
-                for (int rx = 0; rx < RX; rx++) nhwc_unpack<T>(raw[r][rx], row[rx]);
+                for (int rx = 0; rx < RX; rx++) nhwc_unpack2<T>(raw[r][rx], row[rx]);
                 #pragma unroll
                 for (int j = 0; j < MY; j++) {
                     const int my = PY + j * DN;
@@ -596,9 +616,11 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
                         const int ix_first = mx / UP;
                         const int fx_first = (ix_first + 1) * UP - mx - 1;
                         #pragma unroll
-                        for (int kx = fx_first, rx = ix_first; kx < FW; kx += UP, rx++)
+                        for (int kx = fx_first, rx = ix_first; kx < FW; kx += UP, rx++) {
+                            const f2_t tap = {ft[ky][kx], ft[ky][kx]};
                             #pragma unroll
-                            for (int e = 0; e < VEC; e++) acc[j][i][e] = __builtin_fmaf(row[rx][e], ft[ky][kx], acc[j][i][e]);
+                            for (int e = 0; e < VEC / 2; e++) acc[j][i][e] = __builtin_elementwise_fma(row[rx][e], tap, acc[j][i][e]);
+                        }
                     }
                 }
             }
@@ -610,7 +632,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
             #pragma unroll
             for (int i = 0; i < MX; i++) {
                 const unsigned off = (oy < p.out_h && st_off[i] != BAD) ? row_off + st_off[i] : BAD;
-                __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack<T>(acc[j][i]), rout, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack2<T>(acc[j][i]), rout, off, 0, 0);
             }
         }
     }
@@ -675,11 +697,11 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UfParams p, NhwcGrid 
         iy++; in_row_off += in_pitch;
     };
 
-    float acc[FH][VEC];
+    f2_t acc[FH][VEC / 2];
     #pragma unroll
     for (int a = 0; a < FH; a++)
         #pragma unroll
-        for (int e = 0; e < VEC; e++) acc[a][e] = 0.f;
+        for (int e = 0; e < VEC / 2; e++) acc[a][e] = (f2_t){0.f, 0.f};
 
     u32x4_t cur[FW], nxt[FW];
     load_row(cur);
@@ -689,22 +711,24 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UfParams p, NhwcGrid 
             const int j = jb + r;
             if (j >= rows_in) break;
             if (j + 1 < rows_in) load_row(nxt);
-            float row[FW][VEC];
+            f2_t row[FW][VEC / 2];
             #pragma unroll
-            for (int kx = 0; kx < FW; kx++) nhwc_unpack<T>(cur[kx], row[kx]);
+            for (int kx = 0; kx < FW; kx++) nhwc_unpack2<T>(cur[kx], row[kx]);
             #pragma unroll
             for (int ky = 0; ky < FH; ky++) {
                 const int slot = ((r - ky) % FH + FH) % FH;                         // output row j - ky
                 #pragma unroll
-                for (int kx = 0; kx < FW; kx++)
+                for (int kx = 0; kx < FW; kx++) {
+                    const f2_t tap = {ft[ky][kx], ft[ky][kx]};
                     #pragma unroll
-                    for (int e = 0; e < VEC; e++) acc[slot][e] = __builtin_fmaf(row[kx][e], ft[ky][kx], acc[slot][e]);
+                    for (int e = 0; e < VEC / 2; e++) acc[slot][e] = __builtin_elementwise_fma(row[kx][e], tap, acc[slot][e]);
+                }
             }
             const int done = (r + 1) % FH;                                          // output row j - (FH-1) is complete
-            if (j >= FH - 1) __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack<T>(acc[done]), rout, out_row_off + st_off, 0, 0);
+            if (j >= FH - 1) __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack2<T>(acc[done]), rout, out_row_off + st_off, 0, 0);
             out_row_off += (unsigned)out_pitch;
             #pragma unroll
-            for (int e = 0; e < VEC; e++) acc[done][e] = 0.f;
+            for (int e = 0; e < VEC / 2; e++) acc[done][e] = (f2_t){0.f, 0.f};
             #pragma unroll
             for (int kx = 0; kx < FW; kx++) cur[kx] = nxt[kx];
         }
