@@ -32,8 +32,17 @@ def _grad_sync_worker(rank, world, init_file, out_dir):
     params[1].grad[0] = float('nan') if rank == 0 else 1.0            # NaN on one rank -> scrubbed to 0 everywhere
     params[2].grad[0, 0] = float('inf')                                # +inf -> 1e5
     params[3].grad = None if rank == 1 else params[3].grad            # a parameter one rank did not touch
-    PE.GradSync(world_size=world)(params)
+    sync = PE.GradSync(world_size=world)
+    sync(params)
+    assert not sync._agreed                                            # a disagreement is never cached: it is re-checked every time
     torch.save([p.grad.clone() for p in params], os.path.join(out_dir, f'g{rank}.pt'))
+    # second round: every rank has every gradient -> the signature is verified once, then trusted (no read-back per phase)
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1))
+    sync(params)
+    assert len(sync._agreed) == 1
+    sync(params)
+    assert len(sync._agreed) == 1 and all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in params)     # mean(1.5, 1.5): the second call reduced again
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
