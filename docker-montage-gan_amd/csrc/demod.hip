@@ -1,0 +1,113 @@
+// demod.hip -- demodulation coefficients of the (non-fused-weights) modulated convolution and their gradient.
+//
+//   d[n,o] = rsqrt( sum_{i,kh,kw} (w[o,i,kh,kw] * s[n,i])^2 + 1e-8 )
+//          = rsqrt( sum_i s[n,i]^2 * wsq[o,i] + 1e-8 ),   wsq[o,i] = sum_{kh,kw} w[o,i,kh,kw]^2
+// (reference training/networks.py:76-77 on the per-sample weights; as the [N,I] x [I,O] product here).  As separate
+// aten ops this is pow, sum, pow, mm, add, rsqrt forward and nine more kernels backward, 4-10 us each, for every
+// SynthesisLayer call -- about 4 k launches per training step.  Three kernels here: forward (one workgroup per output
+// channel: w[o] is squared and summed on the fly, wsq[o,:] is kept for the backward), gradient w.r.t. the weight
+// (workgroup per output channel) and w.r.t. the styles (workgroup per sample).  All float32.
+#include "mg_common.h"
+
+namespace {
+
+constexpr int DM_MAXN = 256;        // samples per launch (one value per lane slice in LDS)
+
+// block = one output channel o; 256 lanes = 8 slices of the input channels x up to 32 samples per pass
+__global__ void __launch_bounds__(256) demod_fwd_kernel(const float* __restrict__ w, const float* __restrict__ s, float* __restrict__ d,
+                                                       float* __restrict__ wsq, int n, int o_total, int ic, int kk)
+{
+    extern __shared__ float s_wsq[];                // [ic]
+    const int o = blockIdx.x;
+    const float* wp = w + (size_t)o * ic * kk;
+    for (int i = threadIdx.x; i < ic; i += 256) {
+        float a = 0.f;
+        for (int k = 0; k < kk; k++) { const float v = wp[(size_t)i * kk + k]; a = __builtin_fmaf(v, v, a); }
+        s_wsq[i] = a;
+        wsq[(size_t)o * ic + i] = a;
+    }
+    __syncthreads();
+    // each group of 8 lanes handles one sample: lane q of the group sums i = q, q+8, ...
+    const int q = threadIdx.x & 7;
+    for (int nn = threadIdx.x >> 3; nn < n; nn += 32) {
+        const float* sp = s + (size_t)nn * ic;
+        float a = 0.f;
+        for (int i = q; i < ic; i += 8) { const float v = sp[i]; a = __builtin_fmaf(v * v, s_wsq[i], a); }
+        a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+        if (q == 0) d[(size_t)nn * o_total + o] = 1.f / sqrtf(a + 1e-8f);
+    }
+}
+
+// dw[o,i,k] = 2 w[o,i,k] * sum_n t[n,o] s[n,i]^2,  t = -0.5 g d^3.   block = one output channel
+__global__ void __launch_bounds__(256) demod_bwd_w_kernel(const float* __restrict__ w, const float* __restrict__ s, const float* __restrict__ d,
+                                                         const float* __restrict__ g, float* __restrict__ dw, int n, int o_total, int ic, int kk)
+{
+    __shared__ float s_t[DM_MAXN];
+    const int o = blockIdx.x;
+    for (int nn = threadIdx.x; nn < n; nn += 256) {
+        const float dv = d[(size_t)nn * o_total + o];
+        s_t[nn] = -0.5f * g[(size_t)nn * o_total + o] * dv * dv * dv;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ic; i += 256) {
+        float a = 0.f;
+        for (int nn = 0; nn < n; nn++) { const float v = s[(size_t)nn * ic + i]; a = __builtin_fmaf(s_t[nn], v * v, a); }
+        a *= 2.f;
+        const size_t base = ((size_t)o * ic + i) * kk;
+        for (int k = 0; k < kk; k++) dw[base + k] = w[base + k] * a;
+    }
+}
+
+// ds[n,i] = 2 s[n,i] * sum_o t[n,o] wsq[o,i].   block = one sample x 64 input channels; 4 lane groups split the sum over o
+__global__ void __launch_bounds__(256) demod_bwd_s_kernel(const float* __restrict__ s, const float* __restrict__ d, const float* __restrict__ g,
+                                                         const float* __restrict__ wsq, float* __restrict__ ds, int o_total, int ic, int tiles_i)
+{
+    extern __shared__ float s_to[];                 // [o_total] then [4][64] partial sums
+    float* s_red = s_to + o_total;
+    const int nn = blockIdx.x / tiles_i, i = (blockIdx.x % tiles_i) * 64 + (threadIdx.x & 63), os = threadIdx.x >> 6;
+    for (int o = threadIdx.x; o < o_total; o += 256) {
+        const float dv = d[(size_t)nn * o_total + o];
+        s_to[o] = -0.5f * g[(size_t)nn * o_total + o] * dv * dv * dv;
+    }
+    __syncthreads();
+    float a = 0.f;
+    if (i < ic)
+        for (int o = os; o < o_total; o += 4) a = __builtin_fmaf(s_to[o], wsq[(size_t)o * ic + i], a);
+    s_red[os * 64 + (threadIdx.x & 63)] = a;
+    __syncthreads();
+    if (os == 0 && i < ic) {
+        const int il = threadIdx.x & 63;
+        a = (s_red[il] + s_red[64 + il]) + (s_red[128 + il] + s_red[192 + il]);
+        ds[(size_t)nn * ic + i] = 2.f * s[(size_t)nn * ic + i] * a;
+    }
+}
+
+} // namespace
+
+extern "C" int mg_demod_fwd(const float* w, const float* s, float* d, float* wsq, int32_t n, int32_t oc, int32_t ic, int32_t kk,
+                            void* stream)
+{
+    MG_REQUIRE(w && s && d && wsq, "w must reside on the device");
+    MG_REQUIRE(n >= 0 && oc >= 1 && ic >= 1 && kk >= 1 && ic <= 16384, "demod: bad shape");
+    if (n == 0) return MG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    MgLaunchScope scope(MG_K_DEMOD, st, 4.0 * ((double)oc * ic * kk + (double)n * ic + (double)n * oc));
+    hipLaunchKernelGGL(demod_fwd_kernel, dim3((uint32_t)oc), dim3(256), sizeof(float) * (size_t)ic, st, w, s, d, wsq, n, oc, ic, kk);
+    return mg_check_launch(MG_K_DEMOD, "demod_fwd");
+}
+
+extern "C" int mg_demod_bwd(const float* w, const float* s, const float* d, const float* wsq, const float* g, float* ds, float* dw,
+                            int32_t n, int32_t oc, int32_t ic, int32_t kk, void* stream)
+{
+    MG_REQUIRE(w && s && d && wsq && g, "w must reside on the device");
+    MG_REQUIRE(n >= 0 && n <= DM_MAXN && oc >= 1 && oc <= 16384 && ic >= 1 && kk >= 1, "demod: bad shape (at most %d samples)", DM_MAXN);
+    if (n == 0) return MG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    MgLaunchScope scope(MG_K_DEMOD, st, 4.0 * (2.0 * oc * ic * kk + 2.0 * n * ic + 2.0 * n * oc + (double)oc * ic));
+    if (dw) hipLaunchKernelGGL(demod_bwd_w_kernel, dim3((uint32_t)oc), dim3(256), 0, st, w, s, d, g, dw, n, oc, ic, kk);
+    if (ds) {
+        const int tiles_i = (ic + 63) / 64;
+        hipLaunchKernelGGL(demod_bwd_s_kernel, dim3((uint32_t)(n * tiles_i)), dim3(256), sizeof(float) * ((size_t)oc + 256), st, s, d, g, wsq, ds, oc, ic, tiles_i);
+    }
+    return mg_check_launch(MG_K_DEMOD, "demod_bwd");
+}

@@ -22,6 +22,7 @@ import torch
 from ..torch_utils import misc
 from ..torch_utils.ops import bias_act
 from ..torch_utils.ops import conv2d_resample
+from ..torch_utils.ops import demod
 from ..torch_utils.ops import fma
 from ..torch_utils.ops import modconv_epilogue
 from ..torch_utils.ops import upfirdn2d
@@ -41,9 +42,8 @@ def normalize_2nd_moment(x, dim=1, eps=1e-8):
 
 
 def _demod_coefs(weight, styles):
-    """rsqrt(sum_{i,kh,kw} (w[o,i,kh,kw] * s[n,i])^2 + 1e-8) -> [N,O], as one small GEMM."""
-    wsq = weight.square().sum(dim=[2, 3])                   # [O,I]
-    return (styles.square() @ wsq.t() + 1e-8).rsqrt()       # [N,O]
+    """rsqrt(sum_{i,kh,kw} (w[o,i,kh,kw] * s[n,i])^2 + 1e-8) -> [N,O]: one native kernel on the GPU, one small GEMM otherwise."""
+    return demod.demod_coefs(weight, styles)
 
 
 @misc.profiled_function

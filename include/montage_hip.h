@@ -69,7 +69,8 @@ enum {
     MG_K_AFFINE_WARP_FWD = 13,
     MG_K_AFFINE_WARP_BWD = 14,
     MG_K_CHANNEL_MIX = 15,
-    MG_K_COUNT = 16
+    MG_K_DEMOD = 16,
+    MG_K_COUNT = 24
 };
 
 int         mg_abi_version(void);
@@ -173,6 +174,15 @@ int mg_fma_bias_act_nhwc(const void* x, const float* d, const float* noise, cons
 int mg_bwd_fused_nhwc(const void* dy, const void* yref, const void* x, const float* d, const float* noise,
                       void* dx, float* gd, float* gb_partial, float* gs, int dtype, int act, float alpha, float gain,
                       float clamp, int64_t noise_stride_n, int32_t n, int32_t c, int32_t hw, void* stream);
+
+/* ---- demodulation coefficients ---------------------------------------------------
+ * d[n,o] = rsqrt(sum_i s[n,i]^2 * wsq[o,i] + 1e-8), wsq[o,i] = sum_k w[o,i,k]^2 -- the demodulation of
+ * modulated_conv2d (training/networks.py:76-77) for the shared-weight path, float32.
+ * w [O,I,kk] contiguous, s [N,I], d [N,O], wsq [O,I] (written by fwd, read by bwd).
+ * mg_demod_bwd: g = d(loss)/d(d) [N,O]; writes ds [N,I] and / or dw [O,I,kk] (either may be NULL).          */
+int mg_demod_fwd(const float* w, const float* s, float* d, float* wsq, int32_t n, int32_t oc, int32_t ic, int32_t kk, void* stream);
+int mg_demod_bwd(const float* w, const float* s, const float* d, const float* wsq, const float* g, float* ds, float* dw,
+                 int32_t n, int32_t oc, int32_t ic, int32_t kk, void* stream);
 
 /* ---- ADA: affine resampling and colour matrix ------------------------------------
  * mg_affine_warp_fwd:  y = grid_sample(x, affine_grid(theta, [N,C,out_h,out_w], align_corners=False),

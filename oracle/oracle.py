@@ -232,3 +232,25 @@ def channel_mix(x, A, t=None):
     getattr(lib(), 'orc_channel_mix' + _sfx(dt))(_p(x), _p(A), _p(t) if t is not None else None, _p(y), c_int(n), c_int(c),
                                                  ctypes.c_long(hw))
     return y
+
+
+def demod_coefs(w, s):
+    """d[n,o] = rsqrt(sum_{i,kh,kw} (w[o,i,kh,kw] * s[n,i])^2 + 1e-8)  (training/networks.py:76-77 on the per-sample
+    weights w[None] * s[:, None, :, None, None]; evaluated literally that way here, in float64)."""
+    w = np.asarray(w, dtype=np.float64)
+    s = np.asarray(s, dtype=np.float64)
+    per_sample = w[None] * s[:, None, :, None, None]                     # [N,O,I,kh,kw]
+    return 1.0 / np.sqrt((per_sample ** 2).sum(axis=(2, 3, 4)) + 1e-8)
+
+
+def demod_coefs_bwd(w, s, g):
+    """Gradients of sum(d * g) w.r.t. w and s (float64, by the chain rule on the definition above)."""
+    w = np.asarray(w, dtype=np.float64)
+    s = np.asarray(s, dtype=np.float64)
+    g = np.asarray(g, dtype=np.float64)
+    d = demod_coefs(w, s)
+    t = -0.5 * g * d ** 3                                                # d/d(sum of squares)
+    wsq = (w ** 2).sum(axis=(2, 3))                                      # [O,I]
+    ds = 2 * s * (t @ wsq)
+    dw = 2 * w * (t.T @ (s ** 2))[:, :, None, None]
+    return dw, ds

@@ -698,6 +698,37 @@ def test_channel_mix_golden_and_oracle(native, oracle):
         close_lowp(got.float().cpu().numpy(), oracle.channel_mix(x.float().numpy(), A, t), dt, str(shape))
 
 
+def test_demod_coefs_native_vs_oracle(native, oracle):
+    """csrc/demod.hip: demodulation coefficients and both gradients against the float64 oracle (the reference's
+    definition on per-sample weights), the double backward against the composite expression."""
+    D = op('demod')
+    g = torch.Generator().manual_seed(9)
+    k0 = native.launch_count(native.K_DEMOD)
+    for oc, ic, k, n in [(64, 128, 3, 32), (512, 512, 3, 32), (4, 64, 1, 7), (37, 100, 3, 5), (256, 512, 1, 1)]:
+        w = torch.randn([oc, ic, k, k], generator=g).to(DEV).requires_grad_(True)
+        s = (torch.randn([n, ic], generator=g) + 1).to(DEV).requires_grad_(True)
+        d = D.demod_coefs(w, s)
+        gy = torch.randn([n, oc], generator=g).to(DEV)
+        dw, ds = torch.autograd.grad([d], [w, s], [gy])
+        wn, sn = w.detach().cpu().numpy(), s.detach().cpu().numpy()
+        np.testing.assert_allclose(d.detach().cpu().numpy(), oracle.demod_coefs(wn, sn), rtol=2e-5, atol=1e-7)
+        ow, os_ = oracle.demod_coefs_bwd(wn, sn, gy.cpu().numpy())
+        np.testing.assert_allclose(dw.cpu().numpy(), ow, rtol=1e-4, atol=1e-5 * np.abs(ow).max())
+        np.testing.assert_allclose(ds.cpu().numpy(), os_, rtol=1e-4, atol=1e-5 * np.abs(os_).max())
+    assert native.launch_count(native.K_DEMOD) == k0 + 10           # one forward and one backward call per case
+    # second order (path-length regularisation): gradient of a function of d's gradient
+    w = torch.randn([16, 24, 3, 3], generator=g).to(DEV).requires_grad_(True)
+    s = (torch.randn([4, 24], generator=g) + 1).to(DEV).requires_grad_(True)
+    res = []
+    for impl in ('cuda', 'ref'):
+        d = D.demod_coefs(w, s, impl=impl)
+        gs, = torch.autograd.grad([d.square().sum()], [s], create_graph=True)
+        gw2, gs2 = torch.autograd.grad([gs.square().sum()], [w, s])
+        res.append((gs.detach(), gw2, gs2))
+    for a, b in zip(*res):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(b.abs().max()))
+
+
 def test_profiling_hooks_report_kernel_time(native):
     B = op('bias_act')
     x = torch.randn([8, 64, 128, 128], device=DEV)

@@ -254,3 +254,22 @@ def test_affine_warp_and_channel_mix_ref_paths_match_reference():
             dx, = torch.autograd.grad([y], [x], [T(arr[f'm{i}_gy'])])
             np.testing.assert_allclose(y.detach().numpy(), arr[f'm{i}_y'], rtol=1e-5, atol=1e-5)
             np.testing.assert_allclose(dx.numpy(), arr[f'm{i}_dx'], rtol=1e-5, atol=1e-5)
+
+
+def test_demod_coefs_composite_matches_definition(oracle):
+    """The [N,I] x [I,O] form used by the networks equals the reference's definition on per-sample weights
+    (training/networks.py:76-77), values and gradients (CPU: the composite path)."""
+    D = op('demod')
+    g = torch.Generator().manual_seed(5)
+    for oc, ic, k, n in [(6, 5, 3, 4), (8, 16, 1, 3)]:
+        w = torch.randn([oc, ic, k, k], generator=g, dtype=torch.float64, requires_grad=True)
+        s = (torch.randn([n, ic], generator=g, dtype=torch.float64) + 1).requires_grad_(True)
+        d = D.demod_coefs(w, s)
+        ref = (w.unsqueeze(0) * s.reshape(n, 1, ic, 1, 1)).square().sum(dim=[2, 3, 4]).add(1e-8).rsqrt()       # upstream's expression
+        np.testing.assert_allclose(d.detach().numpy(), ref.detach().numpy(), rtol=1e-12)
+        np.testing.assert_allclose(d.detach().numpy(), oracle.demod_coefs(w.detach().numpy(), s.detach().numpy()), rtol=1e-12)
+        gy = torch.randn(d.shape, generator=g, dtype=torch.float64)
+        dw, ds = torch.autograd.grad([d], [w, s], [gy])
+        ow, os_ = oracle.demod_coefs_bwd(w.detach().numpy(), s.detach().numpy(), gy.numpy())
+        np.testing.assert_allclose(dw.numpy(), ow, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(ds.numpy(), os_, rtol=1e-10, atol=1e-12)
