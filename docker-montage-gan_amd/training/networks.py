@@ -25,6 +25,7 @@ from ..torch_utils.ops import conv2d_resample
 from ..torch_utils.ops import demod
 from ..torch_utils.ops import fma
 from ..torch_utils.ops import modconv_epilogue
+from ..torch_utils.ops import small_linear
 from ..torch_utils.ops import upfirdn2d
 from . import weight_prep
 
@@ -123,8 +124,8 @@ class FullyConnectedLayer(torch.nn.Module):
                 if self.bias_gain != 1:
                     b = b * self.bias_gain
         if self.activation == 'linear' and b is not None:
-            return torch.addmm(b.unsqueeze(0), x, w.t())
-        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+            return small_linear.small_linear(x, w, b)                   # torch.addmm(b.unsqueeze(0), x, w.t())
+        return bias_act.bias_act(small_linear.small_linear(x, w), b, act=self.activation)
 
 
 class Conv2dLayer(torch.nn.Module):

@@ -70,6 +70,7 @@ enum {
     MG_K_AFFINE_WARP_BWD = 14,
     MG_K_CHANNEL_MIX = 15,
     MG_K_DEMOD = 16,
+    MG_K_LINEAR = 17,
     MG_K_COUNT = 24
 };
 
@@ -183,6 +184,14 @@ int mg_bwd_fused_nhwc(const void* dy, const void* yref, const void* x, const flo
 int mg_demod_fwd(const float* w, const float* s, float* d, float* wsq, int32_t n, int32_t oc, int32_t ic, int32_t kk, void* stream);
 int mg_demod_bwd(const float* w, const float* s, const float* d, const float* wsq, const float* g, float* ds, float* dw,
                  int32_t n, int32_t oc, int32_t ic, int32_t kk, void* stream);
+
+/* ---- small-batch fully connected layer --------------------------------------------
+ * y[M,O] = x[M,I] @ w[O,I]^T (+ b[O]), float32, M <= 64: FullyConnectedLayer (training/networks.py:104-133:
+ * torch.addmm / matmul on the mapping network, the style affines, the discriminator heads).
+ * mg_linear_bwd: gx[M,I] = g @ w, gw[O,I] = g^T @ x, gb[O] = sum_m g (each output may be NULL).               */
+int mg_linear_fwd(const float* x, const float* w, const float* b, float* y, int32_t m, int32_t ic, int32_t oc, void* stream);
+int mg_linear_bwd(const float* g, const float* x, const float* w, float* gx, float* gw, float* gb,
+                  int32_t m, int32_t ic, int32_t oc, void* stream);
 
 /* ---- ADA: affine resampling and colour matrix ------------------------------------
  * mg_affine_warp_fwd:  y = grid_sample(x, affine_grid(theta, [N,C,out_h,out_w], align_corners=False),

@@ -729,6 +729,41 @@ def test_demod_coefs_native_vs_oracle(native, oracle):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(b.abs().max()))
 
 
+def test_small_linear_native_vs_float64(native):
+    """csrc/linear.hip (FullyConnectedLayer on <= 64 rows): values and all three gradients against a float64 product,
+    ragged sizes (scalar tail path), no bias, and the double backward against the reference expression."""
+    L = op('small_linear')
+    L.enabled = True            # off by default (slower than the BLAS library in its first form); exactness is what is pinned here
+    g = torch.Generator().manual_seed(13)
+    k0 = native.launch_count(native.K_LINEAR)
+    for m, ic, oc, bias in [(32, 512, 512, True), (32, 512, 64, True), (4, 64, 512, False), (7, 100, 37, True), (1, 513, 5, True), (64, 2048, 8, False)]:
+        x = torch.randn([m, ic], generator=g).to(DEV).requires_grad_(True)
+        w = (torch.randn([oc, ic], generator=g) / np.sqrt(ic)).to(DEV).requires_grad_(True)
+        b = torch.randn([oc], generator=g).to(DEV).requires_grad_(True) if bias else None
+        y = L.small_linear(x, w, b)
+        gy = torch.randn([m, oc], generator=g).to(DEV)
+        grads = torch.autograd.grad([y], [x, w] + ([b] if bias else []), [gy])
+        x64, w64, g64 = x.detach().double().cpu(), w.detach().double().cpu(), gy.double().cpu()
+        want = x64 @ w64.t() + (b.detach().double().cpu() if bias else 0)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(grads[0].cpu().numpy(), (g64 @ w64).numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(grads[1].cpu().numpy(), (g64.t() @ x64).numpy(), rtol=1e-4, atol=1e-5)
+        if bias:
+            np.testing.assert_allclose(grads[2].cpu().numpy(), g64.sum(0).numpy(), rtol=1e-4, atol=1e-5)
+    assert native.launch_count(native.K_LINEAR) == k0 + 12
+    x = torch.randn([5, 24], generator=g).to(DEV).requires_grad_(True)
+    w = torch.randn([9, 24], generator=g).to(DEV).requires_grad_(True)
+    b = torch.randn([9], generator=g).to(DEV).requires_grad_(True)
+    res = []
+    for impl in ('cuda', 'ref'):
+        y = L.small_linear(x, w, b, impl=impl)
+        gx, = torch.autograd.grad([y.square().sum()], [x], create_graph=True)
+        res.append(torch.autograd.grad([gx.square().sum()], [x, w, b]))
+    L.enabled = False
+    for a, bb in zip(*res):
+        np.testing.assert_allclose(a.cpu().numpy(), bb.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
 def test_profiling_hooks_report_kernel_time(native):
     B = op('bias_act')
     x = torch.randn([8, 64, 128, 128], device=DEV)
