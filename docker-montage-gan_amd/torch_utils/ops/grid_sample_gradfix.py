@@ -1,56 +1,59 @@
-"""grid_sample (bilinear, zeros padding, align_corners=False) with gradients of any
-order between input and output.
+"""Bilinear ``grid_sample`` (zero padding, align_corners=False) whose input gradient can be differentiated again.
 
-Same interface as the reference (montage_gan/torch_utils/ops/grid_sample_gradfix.py:23,28-32):
-module switch ``enabled`` and ``grid_sample(input, grid)``.  The reference is pinned to
-torch 1.7-1.9 (:37-44) and otherwise falls back to ``F.grid_sample``; this one is written
-against today's ``aten::grid_sampler_2d_backward`` (which takes an output mask) and is the
-op AugmentPipe calls.  As upstream, there is no gradient of the gradient w.r.t. ``grid``.
+Interface of montage_gan/torch_utils/ops/grid_sample_gradfix.py (:23, :28-32): the module switch ``enabled`` and
+``grid_sample(input, grid)``.  Upstream's version only engages on torch 1.7-1.9 (:37-44) and silently becomes
+``F.grid_sample`` elsewhere; this one targets the present ``aten::grid_sampler_2d_backward`` (output-mask signature).
+Sampling is linear in the image, so the adjoint of the image gradient is the sampler itself -- that is all the
+second-order support R1 regularisation through AugmentPipe needs; like upstream there is no second-order term for the
+grid.  (The hot ADA call site no longer comes through here on the GPU: see ops/affine_warp.py.)
 """
 import torch
 
-enabled = False  # Enable the custom op by setting this to true.
+enabled = False     # module switch, as upstream: False -> plain torch.nn.functional.grid_sample
+
+_MODE = dict(mode='bilinear', padding_mode='zeros', align_corners=False)
+_BILINEAR, _ZEROS = 0, 0            # aten enum values of the two settings above
+
+
+def _sample(image, grid):
+    return torch.nn.functional.grid_sample(input=image, grid=grid, **_MODE)
 
 
 def grid_sample(input, grid):
-    if _should_use_custom_op():
-        return _GridSample2dForward.apply(input, grid)
-    return torch.nn.functional.grid_sample(input=input, grid=grid, mode='bilinear', padding_mode='zeros',
-                                           align_corners=False)
+    return _Sampler.apply(input, grid) if enabled else _sample(input, grid)
 
 
-def _should_use_custom_op():
-    return bool(enabled)
-
-
-class _GridSample2dForward(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, input, grid):
-        assert input.ndim == 4 and grid.ndim == 4
-        ctx.save_for_backward(input, grid)
-        return torch.nn.functional.grid_sample(input=input, grid=grid, mode='bilinear', padding_mode='zeros',
-                                               align_corners=False)
+class _Sampler(torch.autograd.Function):
+    """y = sample(image, grid)"""
 
     @staticmethod
-    def backward(ctx, grad_output):
-        input, grid = ctx.saved_tensors
-        return _GridSample2dBackward.apply(grad_output, input, grid)
+    def forward(ctx, image, grid):
+        if image.ndim != 4 or grid.ndim != 4:
+            raise ValueError('grid_sample expects [N,C,H,W] images and [N,Ho,Wo,2] grids')
+        ctx.save_for_backward(image, grid)
+        return _sample(image, grid)
 
-
-class _GridSample2dBackward(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, grad_output, input, grid):
+    def backward(ctx, dy):
+        image, grid = ctx.saved_tensors
+        return _SamplerAdjoint.apply(dy, image, grid)
+
+
+class _SamplerAdjoint(torch.autograd.Function):
+    """(d_image, d_grid) for an upstream gradient dy; differentiable once more w.r.t. dy."""
+
+    @staticmethod
+    def forward(ctx, dy, image, grid):
+        want = [bool(ctx.needs_input_grad[1]), bool(ctx.needs_input_grad[2])]
+        d_image, d_grid = torch.ops.aten.grid_sampler_2d_backward(dy, image, grid, _BILINEAR, _ZEROS, False, want)
         ctx.save_for_backward(grid)
-        mask = [bool(ctx.needs_input_grad[1]), bool(ctx.needs_input_grad[2])]
-        grad_input, grad_grid = torch.ops.aten.grid_sampler_2d_backward(grad_output, input, grid, 0, 0, False, mask)
-        return grad_input, grad_grid
+        return d_image, d_grid
 
     @staticmethod
-    def backward(ctx, grad2_grad_input, grad2_grad_grid):
+    def backward(ctx, dd_image, dd_grid):
+        if ctx.needs_input_grad[2]:
+            raise RuntimeError('no second-order gradient w.r.t. the sampling grid')
         grid, = ctx.saved_tensors
-        grad2_grad_output = None
-        if ctx.needs_input_grad[0]:
-            # the input gradient is linear in grad_output: its adjoint is the forward sampler
-            grad2_grad_output = _GridSample2dForward.apply(grad2_grad_input, grid)
-        assert not ctx.needs_input_grad[2], 'no second-order gradient w.r.t. the sampling grid'
-        return grad2_grad_output, None, None
+        # d_image = A^T dy with A = the (linear) sampling operator  =>  its adjoint applied to dd_image is A dd_image
+        d_dy = _Sampler.apply(dd_image, grid) if ctx.needs_input_grad[0] else None
+        return d_dy, None, None
