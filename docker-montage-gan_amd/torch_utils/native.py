@@ -141,10 +141,23 @@ def dtype_code(torch_dtype):
     return table[torch_dtype]
 
 
+_torch = None
+
+
+def _t():
+    """torch, imported on first use (keeps `import native` light for the ABI-only tests)."""
+    global _torch
+    if _torch is None:
+        import torch
+        _torch = torch
+    return _torch
+
+
 def stream_ptr(device):
-    """Handle of torch's CURRENT stream on `device` (the contract of the reference plugins, upfirdn2d.cpp:92)."""
+    """Handle (int) of torch's CURRENT stream on `device` (the contract of the reference plugins, upfirdn2d.cpp:92)."""
+    torch = _t()
     idx = device.index
-    return _raw_stream(_current_device() if idx is None else idx)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
 
 
 class _NoGuard:
@@ -161,25 +174,11 @@ _no_guard = _NoGuard()
 def guard(device):
     """``torch.cuda.device(device)`` only when `device` is not already the current one (the usual case: one process
     per GPU) -- entering the real guard costs more host time than the launch it protects."""
+    torch = _t()
     idx = device.index
-    if idx is None or idx == _current_device():
+    if idx is None or idx == torch.cuda.current_device():
         return _no_guard
-    import torch
     return torch.cuda.device(device)
-
-
-def _raw_stream(idx):
-    import torch
-    global _raw_stream, _current_device
-    _raw_stream, _current_device = torch._C._cuda_getCurrentRawStream, torch.cuda.current_device     # bind once
-    return _raw_stream(idx)
-
-
-def _current_device():
-    import torch
-    global _raw_stream, _current_device
-    _raw_stream, _current_device = torch._C._cuda_getCurrentRawStream, torch.cuda.current_device
-    return _current_device()
 
 
 def ptr(t):
