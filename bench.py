@@ -60,7 +60,7 @@ def build_trainer(args, device, rank, world):
             kw.global_D_kwargs.block_kwargs.fp16_channels_last = True
         cfg = dict(TL.config, bypass_renderer=True)
         reals = [DS.synthetic_layers(args.batch_gpu, args.layers, args.res, seed=1000 * rank + i, device=device) for i in range(2)]
-        trainer = TL.AioTrainer(rank=rank, device=device, cfg=cfg, resident_batches=reals, random_seed=0, **kw)
+        trainer = TL.AioTrainer(rank=rank, device=device, cfg=cfg, resident_batches=reals, random_seed=0, graphs=args.graphs == 'on', **kw)
         name = (f'train_aio full step: {args.layers} local StyleGAN2 (G+D) + global GAN (STN + alpha composite + D), '
                 f'{args.res}x{args.res} RGBA, bypass_renderer, ' + ('no ADA' if args.no_ada else f'ADA bgc at fixed p={args.ada_p}'))
     else:
@@ -81,7 +81,7 @@ def build_trainer(args, device, rank, world):
         g = torch.Generator(device='cpu').manual_seed(rank)
         reals = [(torch.randint(0, 256, [args.batch_gpu, 4, args.res, args.res], generator=g, dtype=torch.uint8).to(device),
                   torch.zeros([args.batch_gpu, 0], device=device)) for _ in range(2)]
-        trainer = TL.Trainer(rank=rank, device=device, resident_batches=reals, random_seed=0, **kw)
+        trainer = TL.Trainer(rank=rank, device=device, resident_batches=reals, random_seed=0, graphs=args.graphs == 'on', **kw)
         name = f'train.py step: one StyleGAN2 G+D, {args.res}x{args.res} RGBA, ' + ('no ADA' if args.no_ada else f'ADA bgc at fixed p={args.ada_p}')
     return trainer, name
 
@@ -160,6 +160,9 @@ def main():
                          '(~14 min on a fresh box; writes the user db to --miopen-db-out)')
     ap.add_argument('--miopen-find', action='store_true', help='same as --miopen find')
     ap.add_argument('--miopen-db-out', default=None, help='with --miopen find: directory for MIOpen\'s user find-db / perf-db')
+    ap.add_argument('--graphs', default='on', choices=['on', 'off'],
+                    help='record every phase into a HIP graph after 2 eager executions and replay it (phase_engine.PhaseGraphs); '
+                         'implies --ada-margin fixed (a recorded phase cannot read the padding margin back to the host)')
     ap.add_argument('--quiet', action='store_true')
     ap.add_argument('--layout', choices=['nhwc', 'nchw'], default='nhwc',
                     help='memory layout of the reduced-precision blocks (the reference\'s fp16_channels_last option): nhwc keeps MIOpen\'s '
@@ -172,6 +175,8 @@ def main():
     args = ap.parse_args()
     if args.batch_gpu is None:
         args.batch_gpu = 32
+    if args.graphs == 'on' and args.ada_margin != 'fixed':
+        args.ada_margin = 'fixed'
     if args.miopen_find:
         args.miopen = 'find'
     # solver databases must be in place before the first convolution of the process

@@ -1,4 +1,16 @@
-// mg_act.h -- the activation table shared by bias_act.hip and fused.hip.
+// mg_act.h -- pointwise non-linearities of the bias_act family, shared by bias_act.hip and fused.hip.
+//
+// Layout of this file: one `Act<ID>` per activation id of the plugin API (1 = linear ... 9 = swish) exposing
+//     fwd(t, a)          the function itself on the biased input t
+//     slope(u, t, a)     f'   written in terms of the function VALUE u = f(t) where the API saves the output
+//                        (`ref='y'` activations) or of the saved input t (`ref='x'`: swish)
+//     curve(u, t, a)     f''  in the same variables
+// and one driver, ba_eval(), that applies bias, gain, the incoming gradient and the clamp rule around them.
+// What the API fixes (reference bias_act.cu:23-147 for the CUDA statement of the same contract):
+//     order 0:  y = sat(f(x + b) * gain, +-clamp)
+//     order 1:  dx = dy * f'(.) * gain                       where |y_saved| < clamp, else 0
+//     order 2:  d2 = ddx * dy * f''(.) * gain                where |y_saved| < clamp, else 0
+// with one-sided conventions at the kinks taken from the SAVED OUTPUT (u > 0 for relu/lrelu, u >= 0 for elu/selu).
 #pragma once
 #include "mg_common.h"
 
@@ -6,66 +18,82 @@ template <class acc_t> struct BaConst {
     acc_t alpha, gain, clamp;
 };
 
-// One element.  A = activation id 1..9, G = gradient order.
-// Semantics per reference bias_act.cu:51-142.
+template <int ID> struct Act;
+
+template <> struct Act<1> {     // linear
+    template <class R> static __device__ __forceinline__ R fwd(R t, R) { return t; }
+    template <class R> static __device__ __forceinline__ R slope(R, R, R) { return R(1); }
+    template <class R> static __device__ __forceinline__ R curve(R, R, R) { return R(0); }
+};
+template <> struct Act<2> {     // relu
+    template <class R> static __device__ __forceinline__ R fwd(R t, R) { return t > R(0) ? t : R(0); }
+    template <class R> static __device__ __forceinline__ R slope(R u, R, R) { return u > R(0) ? R(1) : R(0); }
+    template <class R> static __device__ __forceinline__ R curve(R, R, R) { return R(0); }
+};
+template <> struct Act<3> {     // leaky relu, negative slope a
+    template <class R> static __device__ __forceinline__ R fwd(R t, R a) { return t > R(0) ? t : t * a; }
+    template <class R> static __device__ __forceinline__ R slope(R u, R, R a) { return u > R(0) ? R(1) : a; }
+    template <class R> static __device__ __forceinline__ R curve(R, R, R) { return R(0); }
+};
+template <> struct Act<4> {     // tanh: f' = 1 - u^2, f'' = -2u f'
+    template <class R> static __device__ __forceinline__ R fwd(R t, R) { return tanh(t); }
+    template <class R> static __device__ __forceinline__ R slope(R u, R, R) { return R(1) - u * u; }
+    template <class R> static __device__ __forceinline__ R curve(R u, R, R) { return (u * u - R(1)) * (u + u); }
+};
+template <> struct Act<5> {     // logistic: f' = u(1-u), f'' = f'(1-2u)
+    template <class R> static __device__ __forceinline__ R fwd(R t, R) { return R(1) / (R(1) + exp(-t)); }       // exp overflow -> 1/inf = 0
+    template <class R> static __device__ __forceinline__ R slope(R u, R, R) { return u - u * u; }
+    template <class R> static __device__ __forceinline__ R curve(R u, R, R) { return (u - u * u) * (R(1) - (u + u)); }
+};
+template <> struct Act<6> {     // elu: on the negative branch u = e^t - 1, so f' = f'' = u + 1
+    template <class R> static __device__ __forceinline__ R fwd(R t, R) { return t >= R(0) ? t : expm1(t); }
+    template <class R> static __device__ __forceinline__ R slope(R u, R, R) { return u >= R(0) ? R(1) : u + R(1); }
+    template <class R> static __device__ __forceinline__ R curve(R u, R, R) { return u >= R(0) ? R(0) : u + R(1); }
+};
+template <> struct Act<7> {     // selu = lam * elu_alpha; negative branch u = lam*alp*(e^t - 1), so f' = f'' = u + lam*alp
+    static constexpr double LAM = 1.05070098735548049342, ALP = 1.67326324235437728482;
+    template <class R> static __device__ __forceinline__ R fwd(R t, R) { return t >= R(0) ? R(LAM) * t : R(LAM * ALP) * expm1(t); }
+    template <class R> static __device__ __forceinline__ R slope(R u, R, R) { return u >= R(0) ? R(LAM) : u + R(LAM * ALP); }
+    template <class R> static __device__ __forceinline__ R curve(R u, R, R) { return u >= R(0) ? R(0) : u + R(LAM * ALP); }
+};
+template <> struct Act<8> {     // softplus u = log(1 + e^t): e^-u = 1 - sigmoid(t), hence f' = 1 - e^-u, f'' = e^-u (1 - e^-u)
+    template <class R> static __device__ __forceinline__ R fwd(R t, R) { return (t > R(0) ? t : R(0)) + log1p(exp(-fabs(t))); }
+    template <class R> static __device__ __forceinline__ R slope(R u, R, R) { return -expm1(-u); }
+    template <class R> static __device__ __forceinline__ R curve(R u, R, R) { R q = exp(-u); return q - q * q; }
+};
+template <> struct Act<9> {     // swish t * s(t), derivatives from the saved INPUT t: f' = s (1 + t (1 - s)), f'' = s (1 - s) (2 + t (1 - 2s))
+    template <class R> static __device__ __forceinline__ R sig(R t) { return R(1) / (R(1) + exp(-t)); }
+    template <class R> static __device__ __forceinline__ R fwd(R t, R) { return t * sig(t); }
+    template <class R> static __device__ __forceinline__ R slope(R, R t, R) { R s = sig(t); return s + t * (s - s * s); }
+    template <class R> static __device__ __forceinline__ R curve(R, R t, R) { R s = sig(t); return (s - s * s) * (R(2) + t * (R(1) - (s + s))); }
+};
+
+// One element.  A = activation id, G = gradient order (0: x is the input; 1: x is the incoming gradient; 2: x is the
+// gradient of the first-order result and dy the original incoming gradient).  xref / yref are the tensors the API saved
+// (0 where it saved none); b is the bias that goes with x (order 0) or with xref (orders 1, 2).
 template <class acc_t, int A>
 __device__ __forceinline__ acc_t ba_eval(int G, acc_t x, acc_t b, acc_t xref, acc_t yref, acc_t dy,
                                          const BaConst<acc_t>& k)
 {
-    const acc_t one = 1, two = 2, expRange = 80, halfExpRange = 40;
-    const acc_t seluScale = (acc_t)1.0507009873554804934193349852946;
-    const acc_t seluAlpha = (acc_t)1.6732632423543772848170429916717;
-    // yy = yref / gain (bias_act.cu:48).  relu/lrelu only ask whether yy > 0, which the sign of gain
-    // answers without an IEEE division per element; linear never reads it.
-    acc_t yy;
-    if (A <= 3) yy = (k.gain > 0) ? yref : (k.gain < 0) ? -yref : 0;
-    else        yy = (k.gain != 0) ? yref / k.gain : 0;
-    acc_t y = 0;
-    if (G == 0) x += b; else xref += b;
-
-    if (A == 1) { if (G <= 1) y = x; }
-    if (A == 2) { if (G == 0) y = (x > 0) ? x : 0; if (G == 1) y = (yy > 0) ? x : 0; }
-    if (A == 3) { if (G == 0) y = (x > 0) ? x : x * k.alpha; if (G == 1) y = (yy > 0) ? x : x * k.alpha; }
-    if (A == 4) {
-        if (G == 0) { acc_t c = exp(x), d = one / c; y = (x < -expRange) ? -one : (x > expRange) ? one : (c - d) / (c + d); }
-        if (G == 1) y = x * (one - yy * yy);
-        if (G == 2) y = x * (one - yy * yy) * (-two * yy);
+    typedef Act<A> F;
+    const acc_t lim = k.clamp;
+    if (G == 0) {
+        acc_t y = F::fwd(x + b, k.alpha) * (k.gain * dy);
+        if (lim >= 0 && !(y > -lim && y < lim)) y = y >= 0 ? lim : -lim;       // saturate (a NaN lands on -clamp, as the API's CUDA statement does)
+        return y;
     }
-    if (A == 5) {
-        if (G == 0) y = (x < -expRange) ? 0 : one / (exp(-x) + one);
-        if (G == 1) y = x * yy * (one - yy);
-        if (G == 2) y = x * yy * (one - yy) * (one - two * yy);
+    const acc_t t = xref + b;
+    acc_t u;                        // the function value before the gain
+    if (A == 9) {                   // saved its input: rebuild the output for the clamp test
+        yref = F::fwd(t, k.alpha) * k.gain;
+        u = 0;
+    } else if (A <= 3) {            // only the SIGN of u matters: gain's sign answers it without a division per element
+        u = k.gain > 0 ? yref : (k.gain < 0 ? -yref : acc_t(0));
+    } else {
+        u = k.gain != 0 ? yref / k.gain : acc_t(0);
     }
-    if (A == 6) {
-        if (G == 0) y = (x >= 0) ? x : exp(x) - one;
-        if (G == 1) y = (yy >= 0) ? x : x * (yy + one);
-        if (G == 2) y = (yy >= 0) ? 0 : x * (yy + one);
-    }
-    if (A == 7) {
-        if (G == 0) y = (x >= 0) ? seluScale * x : (seluScale * seluAlpha) * (exp(x) - one);
-        if (G == 1) y = (yy >= 0) ? x * seluScale : x * (yy + seluScale * seluAlpha);
-        if (G == 2) y = (yy >= 0) ? 0 : x * (yy + seluScale * seluAlpha);
-    }
-    if (A == 8) {
-        if (G == 0) y = (x > expRange) ? x : log(exp(x) + one);
-        if (G == 1) y = x * (one - exp(-yy));
-        if (G == 2) { acc_t c = exp(-yy); y = x * c * (one - c); }
-    }
-    if (A == 9) {
-        if (G == 0) {
-            y = (x < -expRange) ? 0 : x / (exp(-x) + one);
-        } else {
-            acc_t c = exp(xref), d = c + one;
-            if (G == 1) y = (xref > halfExpRange) ? x : x * c * (xref + d) / (d * d);
-            else        y = (xref > halfExpRange) ? 0 : x * c * (xref * (two - d) + two * d) / (d * d * d);
-            yref = (xref < -expRange) ? 0 : xref / (exp(-xref) + one) * k.gain;
-        }
-    }
-    y *= k.gain * dy;
-    if (k.clamp >= 0) {
-        if (G == 0) y = (y > -k.clamp & y < k.clamp) ? y : (y >= 0) ? k.clamp : -k.clamp;
-        else        y = (yref > -k.clamp & yref < k.clamp) ? y : 0;
-    }
+    acc_t d = (G == 1) ? F::slope(u, t, k.alpha) : F::curve(u, t, k.alpha);
+    acc_t y = x * d * (k.gain * dy);
+    if (lim >= 0 && !(yref > -lim && yref < lim)) y = 0;
     return y;
 }
-

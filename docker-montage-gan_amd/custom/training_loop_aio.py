@@ -103,7 +103,8 @@ class AioTrainer:
                  data_loader_kwargs=None, batch_size=4, batch_gpu=4, ema_kimg=10, ema_rampup=None, G_reg_interval=4,
                  D_reg_interval=16, local_G_opt_kwargs=None, local_D_opt_kwargs=None, global_G_opt_kwargs=None,
                  global_D_opt_kwargs=None, loss_kwargs=None, augment_kwargs=None, augment_p=0, ada_target=None,
-                 ada_interval=4, ada_kimg=500, resume_kimg=0.0, cfg=None, rcfg=None, resident_batches=None, **_unused):
+                 ada_interval=4, ada_kimg=500, resume_kimg=0.0, cfg=None, rcfg=None, resident_batches=None, graphs=False,
+                 graph_warmup=1, grad_wire_dtype=None, **_unused):
         cfg = dict(config if cfg is None else cfg)
         rcfg = dict(renderer_config if rcfg is None else rcfg)
         if not cfg['train_global']:
@@ -126,6 +127,13 @@ class AioTrainer:
         conv2d_gradfix.enabled = True
         grid_sample_gradfix.enabled = True
 
+        # graphs=True: every phase is recorded into a HIP graph after `graph_warmup` eager executions and replayed
+        # from then on (phase_engine.PhaseGraphs); needs optimizers whose step counter lives on the device.
+        self.graphs = None
+        if graphs and device.type == 'cuda':
+            self.graphs = phase_engine.PhaseGraphs(device, warmup=graph_warmup)
+        self._static = None         # persistent input tensors of the phases (refreshed in place every iteration)
+
         cci = cfg['conv_config_index']
         local_G_kwargs.conv_config_index = local_D_kwargs.conv_config_index = global_D_kwargs.conv_config_index = cci
         training_set_kwargs.conv_config_index = cci
@@ -134,6 +142,7 @@ class AioTrainer:
 
         # data
         self.training_set = ts = dnnlib.util.construct_class_by_name(**training_set_kwargs)
+        self.training_set_kwargs = dict(training_set_kwargs)
         self.layer_names = ts.layer_names
         self.layer_sizes = [ts.target_res_layer(n) for n in ts.layer_names]
         if cfg['use_global_mapping_network']:
@@ -172,7 +181,8 @@ class AioTrainer:
             if path and os.path.exists(path) and ts.num_layers == rcfg['img_layers']:
                 saved = torch.load(path, map_location=device, weights_only=True)
                 self.renderer.load_state_dict(saved['renderer'] if isinstance(saved, dict) and 'renderer' in saved else saved)
-            opt_renderer = torch.optim.Adam(self.renderer.parameters(), lr=rcfg['lr'], betas=rcfg['betas'], amsgrad=rcfg['amsgrad'])
+            opt_renderer = torch.optim.Adam(self.renderer.parameters(), lr=rcfg['lr'], betas=rcfg['betas'], amsgrad=rcfg['amsgrad'],
+                                            capturable=self.graphs is not None)
             criterion_renderer = torch.nn.MSELoss() if rcfg['loss_type'] == 'mse' else torch.nn.L1Loss()
         self.global_G_ema = dict(mapping_network=copy.deepcopy(self.mapping_network).eval(),
                                  local_G_list=[copy.deepcopy(g).eval() for g in self.local_G_list],
@@ -203,7 +213,7 @@ class AioTrainer:
                                                  self.pos_estimator, self.global_D, self.renderer,
                                                  self.global_G_ema['mapping_network'], *self.global_G_ema['local_G_list'],
                                                  self.global_G_ema['pos_estimator']])
-        self.grad_sync = phase_engine.GradSync(world_size=num_gpus)
+        self.grad_sync = phase_engine.GradSync(world_size=num_gpus, wire_dtype=grad_wire_dtype)
 
         # loss
         lk = dict(device=device, layer_names=self.layer_names, mapping_network=self.mapping_network,
@@ -232,7 +242,7 @@ class AioTrainer:
                           None if G_reg_interval is None else G_reg_interval * goi, goi))
             specs.append(('global_D{}', self.global_D, self.global_D.parameters(), global_D_opt_kwargs,
                           None if D_reg_interval is None else D_reg_interval * goi, goi))
-        self.phases += phase_engine.build_phases(specs, device)
+        self.phases += phase_engine.build_phases(specs, device, capturable=self.graphs is not None)
         for ph in self.phases:
             ph.start_event = ph.end_event = None
             if rank == 0 and device.type == 'cuda':
@@ -248,39 +258,67 @@ class AioTrainer:
             data = next(self._iterator).to(self.device, non_blocking=True)
         return data.detach()
 
+    def _stage_inputs(self):
+        """This iteration's reals and latents, at FIXED addresses (a recorded phase reads them where they were when it
+        was recorded): computed as upstream (:599-612), then copied into persistent tensors with one multi-tensor copy."""
+        device, batch_gpu = self.device, self.batch_gpu
+        data = self._next_reals()                                                           # [B,L,C,H,W] in [0,1]
+        blchw = list(normalize_minus11(data).split(batch_gpu))
+        lists = [make_batch_for_local_d(chunk, layer_size_list=self.layer_sizes, to_minus11=True) for chunk in data.split(batch_gpu)]
+        per_rank = self.batch_size // self.num_gpus
+        if self._static is None:
+            st = self._static = dnnlib.EasyDict()
+            st.blchw = [t.clone() for t in blchw]
+            st.lists = [[t.contiguous().clone() for t in ls] for ls in lists]
+            st.z = torch.empty([len(self.phases) * per_rank, self.mapping_network.z_dim], device=device)
+            st.z_rounds = [z.split(batch_gpu) for z in st.z.split(per_rank)]
+            st.flat = st.blchw + [t for ls in st.lists for t in ls]
+        else:
+            st = self._static
+            torch._foreach_copy_(st.flat, blchw + [t for ls in lists for t in ls])
+        st.z.normal_()
+        return st
+
+    def _run_phase(self, phase, st, gen_z_rounds):
+        rounds = len(st.blchw)
+
+        def accumulate():
+            for round_idx, (real_layer, gen_z, real_list) in enumerate(zip(st.blchw, gen_z_rounds, st.lists)):
+                self.loss.accumulate_gradients(phase=phase.name, real_blchw=real_layer, real_list_of_bchw=real_list, gen_z=gen_z,
+                                               sync=(round_idx == rounds - 1), gain=phase.interval)
+        phase_engine.run_phase(phase, accumulate, self.grad_sync, self.graphs, self.num_gpus)
+
     def run_iteration(self):
         """One loop iteration (reference :597-688): data, every phase whose interval divides batch_idx,
         EMA, ADA.  Returns the number of phases executed."""
-        device, batch_gpu = self.device, self.batch_gpu
+        device = self.device
         with torch.autograd.profiler.record_function('data_fetch'):
-            data = self._next_reals()                                                       # [B,L,C,H,W] in [0,1]
-            phase_real_blchw = normalize_minus11(data).split(batch_gpu)
-            phase_real_lists = [make_batch_for_local_d(chunk, layer_size_list=self.layer_sizes, to_minus11=True)
-                                for chunk in data.split(batch_gpu)]
-            all_gen_z = torch.randn([len(self.phases) * self.batch_size // self.num_gpus, self.mapping_network.z_dim], device=device)
-            all_gen_z = [z.split(batch_gpu) for z in all_gen_z.split(self.batch_size // self.num_gpus)]
+            st = self._stage_inputs()
         ran = 0
-        rounds = len(phase_real_blchw)
-        for phase, phase_gen_z in zip(self.phases, all_gen_z):
+        for phase, gen_z_rounds in zip(self.phases, st.z_rounds):
             if self.batch_idx % phase.interval != 0:
                 continue
             if phase.start_event is not None:
                 phase.start_event.record(torch.cuda.current_stream(device))
-            phase.begin()
-            for round_idx, (real_layer, gen_z, real_list) in enumerate(zip(phase_real_blchw, phase_gen_z, phase_real_lists)):
-                self.loss.accumulate_gradients(phase=phase.name, real_blchw=real_layer, real_list_of_bchw=real_list, gen_z=gen_z,
-                                               sync=(round_idx == rounds - 1), gain=phase.interval)
-            phase.finish(self.grad_sync)
+            self._run_phase(phase, st, gen_z_rounds)
             if phase.end_event is not None:
                 phase.end_event.record(torch.cuda.current_stream(device))
+                phase['_timed'] = True
             ran += 1
 
         with torch.autograd.profiler.record_function('global_G_ema'):
             beta = phase_engine.ema_beta_for(self.batch_size, self.cur_nimg, self.ema_kimg, self.ema_rampup)
-            phase_engine.update_ema(self.global_G_ema['mapping_network'], self.mapping_network, beta)
-            phase_engine.update_ema(self.global_G_ema['local_G_list'], self.local_G_list, beta)
-            if self.pos_estimator is not None:
-                phase_engine.update_ema(self.global_G_ema['pos_estimator'], self.pos_estimator, beta)
+
+            def ema():
+                phase_engine.update_ema(self.global_G_ema['mapping_network'], self.mapping_network, beta)
+                phase_engine.update_ema(self.global_G_ema['local_G_list'], self.local_G_list, beta)
+                if self.pos_estimator is not None:
+                    phase_engine.update_ema(self.global_G_ema['pos_estimator'], self.pos_estimator, beta)
+            if self.graphs is not None and beta == getattr(self, '_ema_beta_prev', None):
+                self.graphs.run(('ema', beta), ema)         # constant beta (no ramp-up, or past it): record once
+            else:
+                ema()
+            self._ema_beta_prev = beta
         self.cur_nimg += self.batch_size
         self.batch_idx += 1
 
@@ -289,24 +327,59 @@ class AioTrainer:
                                      self.augment_pipe_list + [self.global_augment_pipe]):
             if stats is not None and self.batch_idx % self.ada_interval == 0:
                 stats.update()
-                adjust = np.sign(stats[f'{name}/Loss/signs/real'] - self.ada_target) * (self.batch_size * self.ada_interval) / (self.ada_kimg * 1000)
+                adjust = phase_engine.ada_adjust(stats[f'{name}/Loss/signs/real'], self.ada_target, self.batch_size, self.ada_interval, self.ada_kimg)
                 pipe.p.copy_((pipe.p + adjust).max(misc.constant(0, device=device)).min(misc.constant(self.cfg['aug_p_max'], device=device)))
         return ran
 
-    def state_dicts(self):
-        """Snapshot under the reference's names (:809-833)."""
-        out = dict(mapping_network=self.mapping_network.state_dict(),
-                   mapping_network_ema=self.global_G_ema['mapping_network'].state_dict(),
-                   local_G_list=[g.state_dict() for g in self.local_G_list],
-                   local_G_ema_list=[g.state_dict() for g in self.global_G_ema['local_G_list']],
-                   local_D_list=[d.state_dict() for d in self.local_D_list],
-                   augment_pipe_list=[p.state_dict() if p is not None else None for p in self.augment_pipe_list])
-        if self.pos_estimator is not None:
-            out.update(pos_estimator=self.pos_estimator.state_dict(), pos_estimator_ema=self.global_G_ema['pos_estimator'].state_dict(),
-                       global_D=self.global_D.state_dict())
+    def _snapshot_modules(self):
+        """(name, module or list of modules) in the reference's order and under its names (:809-826)."""
+        mods = [('mapping_network', self.mapping_network), ('local_G_list', self.local_G_list), ('local_D_list', self.local_D_list)]
         if self.renderer is not None:
-            out.update(renderer=self.renderer.state_dict())
+            mods.append(('renderer', self.renderer))
+        mods += [('mapping_network_ema', self.global_G_ema['mapping_network']), ('local_G_ema', self.global_G_ema['local_G_list']),
+                 ('augment_pipe_list', self.augment_pipe_list)]
+        if self.pos_estimator is not None:
+            mods += [('pos_estimator', self.pos_estimator), ('pos_estimator_ema', self.global_G_ema['pos_estimator']),
+                     ('global_augment_pipe', self.global_augment_pipe), ('global_D', self.global_D)]
+        return mods
+
+    def state_dicts(self):
+        """Snapshot: a dict of ``state_dict``s under the reference's names (:809-833), plus ``training_set_kwargs``."""
+        def sd(m):
+            return [sd(x) for x in m] if isinstance(m, list) else (None if m is None else copy.deepcopy(m.state_dict()))
+        out = dict(training_set_kwargs=dict(self.training_set_kwargs))
+        for name, module in self._snapshot_modules():
+            out[name] = sd(module)
         return out
+
+    def load_state_dicts(self, saved):
+        """Resume (:345-366): every module the reference restores, missing entries skipped; a plain ``MappingNetwork``
+        state is tiled into the ``GlobalMappingNetwork`` where the sizes differ (:319-331).  Returns the names restored."""
+        restored = []
+        resumable = ('mapping_network', 'local_G_list', 'local_D_list', 'renderer', 'mapping_network_ema', 'local_G_ema',
+                     'pos_estimator', 'pos_estimator_ema', 'global_D')
+        for name, module in self._snapshot_modules():
+            data = saved.get(name)
+            if name not in resumable or data is None or module is None:
+                continue
+            if isinstance(module, list):
+                assert len(module) == len(data), name
+                for m, d in zip(module, data):
+                    m.load_state_dict(d)
+            elif hasattr(module, 'num_splits'):
+                cur, new = module.state_dict(), {}
+                for k, v in zip(cur.keys(), data.values()):
+                    if v.size() == cur[k].size():
+                        new[k] = v
+                    else:           # one latent stack -> one per image layer
+                        rep = [1] * v.dim()
+                        rep[0] = module.num_splits
+                        new[k] = v.repeat(*rep)
+                module.load_state_dict(new)
+            else:
+                module.load_state_dict(data)
+            restored.append(name)
+        return restored
 
 
 def training_loop(rank=0, run_dir='.', random_seed=0, num_gpus=1, kimg_per_tick=4, image_snapshot_ticks=50,
@@ -336,12 +409,9 @@ def training_loop(rank=0, run_dir='.', random_seed=0, num_gpus=1, kimg_per_tick=
                          augment_kwargs=augment_kwargs, augment_p=augment_p, ada_target=ada_target, ada_interval=ada_interval,
                          ada_kimg=ada_kimg, resume_kimg=resume_kimg)
     if resume_pkl is not None:
+        # every rank reads the same file (upstream: rank 0 loads, the DDP constructor broadcasts), so all ranks agree
         saved = torch.load(resume_pkl, map_location=trainer.device, weights_only=True)
-        trainer.mapping_network.load_state_dict(saved['mapping_network'])
-        for g, sd in zip(trainer.local_G_list, saved['local_G_list']):
-            g.load_state_dict(sd)
-        for d, sd in zip(trainer.local_D_list, saved['local_D_list']):
-            d.load_state_dict(sd)
+        trainer.load_state_dicts(saved)
     stats_collector = training_stats.Collector(regex='.*')
     stats_jsonl = open(os.path.join(run_dir, 'stats.jsonl'), 'wt') if rank == 0 else None
     cur_tick, tick_start_nimg, tick_start_time = 0, trainer.cur_nimg, time.time()
@@ -362,8 +432,12 @@ def training_loop(rank=0, run_dir='.', random_seed=0, num_gpus=1, kimg_per_tick=
         if rank == 0 and network_snapshot_ticks is not None and (done or cur_tick % network_snapshot_ticks == 0):
             torch.save(trainer.state_dicts(), os.path.join(run_dir, f'network-snapshot-{trainer.cur_nimg // 1000:06d}.pth'))
         for ph in trainer.phases:
-            if ph.start_event is not None and ph.end_event.query():
-                training_stats.report0('Timing/' + ph.name, ph.start_event.elapsed_time(ph.end_event))
+            # every rank registers every name (rank != 0 reports nothing under it): Collector._sync all-reduces one
+            # [n_names, 3] tensor, so the name tables must have the same length everywhere (reference :411-416)
+            value = []
+            if ph.start_event is not None and ph.get('_timed') and ph.end_event.query():
+                value = ph.start_event.elapsed_time(ph.end_event)
+            training_stats.report0('Timing/' + ph.name, value)
         stats_collector.update()
         if stats_jsonl is not None:
             stats_jsonl.write(json.dumps(dict(stats_collector.as_dict(), timestamp=time.time())) + '\n')

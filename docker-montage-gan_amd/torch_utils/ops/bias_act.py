@@ -132,7 +132,8 @@ def _bias_act_cuda(dim=1, act='linear', alpha=None, gain=None, clamp=None):
             # Plain first-order backward of the network layers (NCHW or NHWC, bias on dim 1, piecewise-linear activation):
             # ONE native pass writes dx and leaves sum(dx) per channel in a float32 accumulator, instead of the
             # gradient kernel followed by a separate reduction over dx (upstream :186-196).
-            if (ctx.needs_input_grad[1] and not torch.is_grad_enabled() and not is_identity and idx <= 3 and dim == 1
+            # (linear saves no output, so the kernel has nothing to evaluate the gain against: only gain == 1 qualifies)
+            if (ctx.needs_input_grad[1] and not torch.is_grad_enabled() and not is_identity and (idx in (2, 3) or (idx == 1 and gain == 1)) and dim == 1
                     and dy.ndim == 4 and dy.dtype != torch.float64 and dy.numel() > 0):
                 n, c, h, w = dy.shape
                 vec = 16 // dy.element_size()

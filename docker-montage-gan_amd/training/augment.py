@@ -264,7 +264,10 @@ class AugmentPipe(torch.nn.Module):
                 return np.asarray([[sx, 0, 0], [0, sy, 0], [0, 0, 1]], dtype=f32)
             left = S(2 / images.shape[3], 2 / images.shape[2]) @ (T(-0.5, -0.5) @ (S(2, 2) @ T((mx0 - mx1) / 2, (my0 - my1) / 2)))
             right = (S(1 / 2, 1 / 2) @ T(0.5, 0.5)) @ S(1 / (2 / shape[3]), 1 / (2 / shape[2]))
-            lr = misc.upload_small(np.stack([left, right]), dev)
+            if fixed_margin:        # host-known constants of the CONFIGURATION: cached on the device (also keeps the call recordable into a HIP graph)
+                lr = misc.constant(np.stack([left, right]), device=dev)
+            else:
+                lr = misc.upload_small(np.stack([left, right]), dev)
             G_inv = lr[0] @ G_inv @ lr[1]
             images = affine_warp.affine_warp(images, G_inv[:, :2, :], shape[2], shape[3])     # affine_grid + grid_sample, one pass
             # back down, cropping the filter margin

@@ -43,54 +43,111 @@ def _params_of(module):
 
 
 class GradSync:
-    """Gradient post-processing for one optimizer step: cross-rank mean + NaN/Inf scrub."""
+    """Gradient post-processing for one optimizer step: cross-rank mean + NaN/Inf scrub.
 
-    def __init__(self, world_size=1, process_group=None):
-        self.world_size, self.process_group = world_size, process_group
-        self._agreed = set()      # gradient signatures all ranks were seen to share
+    Each optimizer owns ONE persistent flat float32 buffer (allocated on first use, shared by its main and reg
+    phase).  ``pack`` gathers the phase's gradients into it with a single multi-tensor copy, ``exchange`` is the
+    one all-reduce(SUM)/N of the phase (skipped on one GPU), ``unpack`` scrubs the buffer in place and re-points
+    every ``p.grad`` at its slice of the buffer -- the optimizer reads the reduced values where they lie, nothing is
+    copied back.  ``wire_dtype=torch.bfloat16`` halves the bytes on the xGMI links (sum in bf16, off by default).
+    The three stages are separate so that a phase recorded into HIP graphs can keep the collective outside them.
+    """
 
+    VERIFY_FIRST = 2        # signature checks per optimizer key; a call COUNT, hence identical on every rank
+
+    def __init__(self, world_size=1, process_group=None, wire_dtype=None):
+        self.world_size, self.process_group, self.wire_dtype = world_size, process_group, wire_dtype
+        self._flat = dict()         # key -> persistent flat buffer
+        self._layout = dict()       # key -> tuple of (param index, offset, numel) of the gradients packed last
+        self._verified = dict()     # key -> number of signature checks done
+
+    # -- stages ------------------------------------------------------------------------------------
     @torch.no_grad()
-    def __call__(self, params):
-        grads = [p.grad for p in params if p.grad is not None]
+    def pack(self, params, key=None):
+        """Gradients of `params` -> the persistent flat buffer of `key`.  Returns the packed view or None."""
+        key = id(params) if key is None else key
+        present = [i for i, p in enumerate(params) if p.grad is not None]
         if self.world_size > 1:
-            # Every rank runs the same phase code, so the SAME parameters carry gradients everywhere (a phase that
-            # computes nothing -- global_Greg upstream -- leaves them all None and Adam skips them, as on one GPU).
-            # One tiny all-reduce checks that before the big one; a mismatch would otherwise hang or mis-add.  Which
-            # parameters get a gradient is a property of the phase's code path, not of the data, so each distinct
-            # signature is verified once (the comparison reads the result back, i.e. it drains the launch queue:
-            # doing it every phase would serialise host and device 36 times per step).
-            key = (len(params), len(grads), sum(g.numel() for g in grads))
-            agree = key in self._agreed
-            if not agree:
-                sig = torch.tensor(key[1:], dtype=torch.int64, device=self._device(params))
-                lo, hi = sig.clone(), sig.clone()
-                torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
-                torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=self.process_group)
-                agree = torch.equal(lo, hi)
-                if agree:
-                    self._agreed.add(key)
-            if not agree:
-                # ranks disagree: fall back to the union, missing gradients count as zeros
-                grads = []
-                for p in params:
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
-                    grads.append(p.grad)
-        if not grads:
-            return 0
-        flat = torch._utils._flatten_dense_tensors(grads)
-        if self.world_size > 1:
-            torch.distributed.all_reduce(flat, group=self.process_group)
-            flat.div_(self.world_size)
-        torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)
-        torch._foreach_copy_(grads, list(torch._utils._unflatten_dense_tensors(flat, grads)))
-        return flat.numel()
+            present = self._agree(params, present, key)
+        if not present:
+            self._layout[key] = ()
+            return None
+        total = sum(params[i].numel() for i in present)
+        flat = self._flat.get(key)
+        if flat is None or flat.numel() < total:
+            cap = sum(p.numel() for p in params)
+            flat = self._flat[key] = torch.empty([cap], dtype=torch.float32, device=params[present[0]].device)
+        layout, off = [], 0
+        for i in present:
+            layout.append((i, off, params[i].numel()))
+            off += params[i].numel()
+        self._layout[key] = tuple(layout)
+        torch._foreach_copy_([self._slice(flat, params[i], o) for i, o, n in layout], [params[i].grad for i in present])
+        return flat[:total]
 
     @staticmethod
-    def _device(params):
+    def _slice(flat, p, offset):
+        """The slice of the flat buffer that stands for p's gradient, with p's own (dense) strides -- channels-last
+        weights keep their layout, which the fused optimizer requires of (param, grad) pairs."""
+        return torch.as_strided(flat, p.size(), p.stride(), offset)
+
+    @torch.no_grad()
+    def exchange(self, flat):
+        if flat is None or self.world_size <= 1:
+            return
+        if self.wire_dtype is not None and self.wire_dtype != flat.dtype:
+            wire = flat.to(self.wire_dtype)
+            torch.distributed.all_reduce(wire, group=self.process_group)
+            flat.copy_(wire)
+        else:
+            torch.distributed.all_reduce(flat, group=self.process_group)
+        flat.div_(self.world_size)
+
+    @torch.no_grad()
+    def unpack(self, params, flat, key=None):
+        """nan_to_num(nan=0, posinf=1e5, neginf=-1e5) on the whole buffer (one kernel instead of one per parameter,
+        reference training_loop.py:310-312), then p.grad = its slice."""
+        key = id(params) if key is None else key
+        if flat is None:
+            return 0
+        torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)
+        full = self._flat[key]
+        for i, o, n in self._layout[key]:
+            params[i].grad = self._slice(full, params[i], o)
+        return flat.numel()
+
+    def __call__(self, params, key=None):
+        flat = self.pack(params, key)
+        self.exchange(flat)
+        return self.unpack(params, flat, key)
+
+    # -- cross-rank agreement ------------------------------------------------------------------------
+    def _agree(self, params, present, key):
+        """Every rank runs the same phase code, so the SAME parameters carry gradients everywhere (a phase that
+        computes nothing -- global_Greg upstream -- leaves them all None and Adam skips them, as on one GPU).  A
+        mismatch would mis-add or hang the big all-reduce, so the first VERIFY_FIRST packs of every key compare a
+        signature (count, numel, CRC of the presence bitmap) across ranks with one small MAX all-reduce of
+        [sig, -sig].  Whether the check runs depends only on the call count -- the same on every rank -- never on a
+        rank-local cache of outcomes.  On disagreement the union is used: missing gradients count as zeros."""
+        done = self._verified.get(key, 0)
+        if done >= self.VERIFY_FIRST or (params and params[0].is_cuda and torch.cuda.is_current_stream_capturing()):
+            return present          # (a recording happens at the same call count on every rank, so this is rank-consistent too)
+        self._verified[key] = done + 1
+        import zlib
+        bitmap = bytearray(len(params))
+        for i in present:
+            bitmap[i] = 1
+        sig = [len(present), sum(params[i].numel() for i in present), zlib.crc32(bytes(bitmap))]
+        dev = params[0].device if params else torch.device('cpu')
+        t = torch.tensor(sig + [-v for v in sig], dtype=torch.int64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.process_group)
+        t = t.tolist()
+        if all(t[j] == -t[j + 3] for j in range(3)):
+            return present
         for p in params:
-            return p.device
-        return torch.device('cpu')
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        return list(range(len(params)))
 
 
 class Phase(dnnlib.EasyDict):
@@ -107,25 +164,71 @@ class Phase(dnnlib.EasyDict):
             if m is not None:
                 m.requires_grad_(True)
 
-    def finish(self, grad_sync):
+    def end_backward(self):
         for m in _modules_of(self.module):
             if m is not None:
                 m.requires_grad_(False)
+
+    def step_params(self):
+        """The parameters the optimizer owns (what the reference's nan_to_num loop walks, training_loop.py:310)."""
+        if '_step_params' not in self:
+            self['_step_params'] = [p for g in self.opt.param_groups for p in g['params']]
+        return self['_step_params']
+
+    def finish(self, grad_sync):
+        self.end_backward()
         with torch.autograd.profiler.record_function(self.name + '_opt'):
-            grad_sync(self.params())
+            grad_sync(self.step_params(), key=id(self.opt))
             self.opt.step()
 
 
-def make_optimizer(params, opt_kwargs, device):
+def run_phase(phase, accumulate, grad_sync, graphs=None, world_size=1):
+    """One phase of the loop (reference training_loop.py:288-317): zero_grad + requires_grad on, ``accumulate()`` (every
+    accumulation round's forward/backward), requires_grad off, gradient exchange + scrub, optimizer step -- eagerly, or
+    through ``graphs`` (PhaseGraphs).  With more than one rank the collective stays between two recorded halves."""
+    params, key = phase.step_params(), id(phase.opt)
+
+    def forward_backward():
+        phase.begin()
+        accumulate()
+        phase.end_backward()
+        phase['_flat'] = grad_sync.pack(params, key)
+
+    def step():
+        grad_sync.unpack(params, phase['_flat'], key)
+        phase.opt.step()
+
+    def has_work():
+        # a phase that computes nothing (global_Greg upstream, SURVEY App. B-5) has nothing to record
+        return phase['_flat'] is not None
+
+    if graphs is None:
+        with torch.autograd.profiler.record_function(phase.name):
+            forward_backward()
+            grad_sync.exchange(phase['_flat'])
+            step()
+    elif world_size == 1:
+        graphs.run(phase.name, lambda: (forward_backward(), step()), record_if=has_work)
+    else:
+        graphs.run((phase.name, 'fwd_bwd'), forward_backward, record_if=has_work)
+        grad_sync.exchange(phase['_flat'])
+        graphs.run((phase.name, 'step'), step, record_if=has_work)
+
+
+def make_optimizer(params, opt_kwargs, device, capturable=False):
     """construct_class_by_name on the caller's kwargs; on the GPU torch.optim.Adam is asked for its
     fused (single multi-tensor kernel) implementation unless the caller decided otherwise."""
     kw = dict(opt_kwargs)
+    if 'betas' in kw and not any(isinstance(b, torch.Tensor) for b in kw['betas']):
+        kw['betas'] = tuple(float(b) for b in kw['betas'])          # upstream passes [0, 0.99]: today's Adam rejects an int beta
     if kw.get('class_name') == 'torch.optim.Adam' and torch.device(device).type == 'cuda' and 'fused' not in kw and 'foreach' not in kw:
         kw['fused'] = True
+        if capturable:          # step counter on the device: the step can be recorded into a HIP graph (same arithmetic)
+            kw.setdefault('capturable', True)
     return dnnlib.util.construct_class_by_name(params, **kw)
 
 
-def build_phases(specs, device):
+def build_phases(specs, device, capturable=False):
     """specs: iterable of (name_fmt, module_or_list, params, opt_kwargs, reg_interval, main_interval) where
     name_fmt has one '{}' for the phase kind ('G{}' -> 'Gmain', 'local_D{}_hair' -> 'local_Dreg_hair').
     Returns the Phase list in execution order: 'both', or 'main' followed by 'reg', per spec."""
@@ -133,14 +236,14 @@ def build_phases(specs, device):
     for name, module, params, opt_kwargs, reg_interval, main_interval in specs:
         params = list(params)
         if reg_interval is None:
-            opt = make_optimizer(params, opt_kwargs, device)
+            opt = make_optimizer(params, opt_kwargs, device, capturable)
             phases.append(Phase(name=name.format('both'), module=module, opt=opt, interval=main_interval))
         else:
             mb_ratio = reg_interval / (reg_interval + 1)
             kw = dnnlib.EasyDict(opt_kwargs)
             kw.lr = kw.lr * mb_ratio
             kw.betas = [beta ** mb_ratio for beta in kw.betas]
-            opt = make_optimizer(params, kw, device)
+            opt = make_optimizer(params, kw, device, capturable)
             phases.append(Phase(name=name.format('main'), module=module, opt=opt, interval=main_interval))
             phases.append(Phase(name=name.format('reg'), module=module, opt=opt, interval=reg_interval))
     return phases
@@ -167,6 +270,13 @@ def ema_beta_for(batch_size, cur_nimg, ema_kimg, ema_rampup):
     return 0.5 ** (batch_size / max(ema_nimg, 1e-8))
 
 
+def ada_adjust(signs_real_mean, ada_target, batch_size, ada_interval, ada_kimg):
+    """Increment of the augmentation probability: sign(E[sign(D(real))] - target) * batch * interval / (ada_kimg * 1000)
+    (reference training_loop.py:333-337)."""
+    import numpy as np
+    return float(np.sign(signs_real_mean - ada_target) * (batch_size * ada_interval) / (ada_kimg * 1000))
+
+
 def broadcast_module_state(modules, src=0):
     """What the DDP constructor does at start-up: every rank takes rank 0's parameters and buffers."""
     for m in _modules_of(modules):
@@ -174,3 +284,60 @@ def broadcast_module_state(modules, src=0):
             continue
         for t in misc.params_and_buffers(m):
             torch.distributed.broadcast(t.detach(), src=src)
+
+
+class PhaseGraphs:
+    """Whole phases recorded into HIP graphs and replayed.
+
+    A phase of the loop (reference training_loop.py:288-317: zero_grad, forward, backward of every accumulation
+    round, gradient post-processing, optimizer step) is ~1-3 thousand kernel launches whose arguments never change
+    between iterations once the inputs live at fixed addresses: the host spends more time issuing them than the
+    MI355X spends executing them at small per-GPU batches.  ``run(phase, body, sync_body)`` executes ``body`` eagerly
+    the first ``warmup`` times a phase fires (solver selection, lazy state, statistics counters), then records it
+    once on a capture stream (``hipStreamBeginCapture`` through torch.cuda.graph) and from then on replays the graph:
+    one host call per phase.  Everything a body reads must be a persistent tensor that the caller refreshes in
+    place (reals, latents); everything it updates (parameters, Adam moments and step counters, EMA inputs, ``pl_mean``,
+    ``w_avg``, statistics counters, the ADA probability ``p``) is device state updated by the recorded kernels.
+
+    Multi-GPU: a collective is not recorded.  The phase is split at the gradient exchange -- graph 1 ends with the
+    gradients packed into the phase's persistent flat buffer, the all-reduce runs eagerly on the same stream, graph 2
+    (scrub, scatter, optimizer step) follows.
+    All graphs share one memory pool: they replay strictly one after another on one stream.
+    """
+
+    def __init__(self, device, warmup=1):
+        self.device = torch.device(device)
+        self.warmup = warmup
+        self._seen = dict()         # key -> eager executions so far
+        self._graphs = dict()       # key -> torch.cuda.CUDAGraph
+        self._pool = None
+        self._stream = None
+        self.captured = 0
+        self.replays = 0
+
+    def _capture(self, fn):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+            self._pool = torch.cuda.graph_pool_handle()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self._pool, stream=self._stream):
+            fn()
+        self.captured += 1
+        return g
+
+    def run(self, key, fn, record_if=None):
+        """Execute fn(): eagerly the first `warmup` times, through its graph afterwards.  The recording is made right
+        after the last eager execution (recording executes nothing on the device), so a phase that fires rarely --
+        Dreg, every 16th iteration -- is replayed from its second firing on instead of being recorded in the middle
+        of the run.  Returns True when the graph was replayed."""
+        g = self._graphs.get(key)
+        if g is not None:
+            g.replay()
+            self.replays += 1
+            return True
+        n = self._seen.get(key, 0) + 1
+        self._seen[key] = n
+        fn()
+        if n >= self.warmup and (record_if is None or record_if()):
+            self._graphs[key] = self._capture(fn)
+        return False

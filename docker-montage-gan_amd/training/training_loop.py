@@ -53,7 +53,7 @@ class Trainer:
                  G_kwargs=None, D_kwargs=None, G_opt_kwargs=None, D_opt_kwargs=None, augment_kwargs=None, loss_kwargs=None,
                  batch_size=4, batch_gpu=4, ema_kimg=10, ema_rampup=None, G_reg_interval=4, D_reg_interval=16, augment_p=0,
                  ada_target=None, ada_interval=4, ada_kimg=500, cudnn_benchmark=True, allow_tf32=False, resident_batches=None,
-                 **_unused):
+                 graphs=False, graph_warmup=1, grad_wire_dtype=None, **_unused):
         self.rank, self.num_gpus = rank, num_gpus
         self.device = device = torch.device('cuda', rank) if device is None else torch.device(device)
         self.batch_size, self.batch_gpu = batch_size, batch_gpu
@@ -87,11 +87,15 @@ class Trainer:
                 self.ada_stats = training_stats.Collector(regex='Loss/signs/real')
         if num_gpus > 1:
             phase_engine.broadcast_module_state([self.G, self.D, self.G_ema])
-        self.grad_sync = phase_engine.GradSync(world_size=num_gpus)
+        self.grad_sync = phase_engine.GradSync(world_size=num_gpus, wire_dtype=grad_wire_dtype)
+        # graphs=True: phases are recorded into HIP graphs after `graph_warmup` eager executions (phase_engine.PhaseGraphs)
+        self.graphs = phase_engine.PhaseGraphs(device, warmup=graph_warmup) if graphs and device.type == 'cuda' else None
+        self._static = None
         self.loss = dnnlib.util.construct_class_by_name(device=device, G_mapping=self.G.mapping, G_synthesis=self.G.synthesis,
                                                         D=self.D, augment_pipe=self.augment_pipe, **loss_kwargs)
         self.phases = phase_engine.build_phases([('G{}', self.G, self.G.parameters(), G_opt_kwargs, G_reg_interval, 1),
-                                                 ('D{}', self.D, self.D.parameters(), D_opt_kwargs, D_reg_interval, 1)], device)
+                                                 ('D{}', self.D, self.D.parameters(), D_opt_kwargs, D_reg_interval, 1)], device,
+                                                capturable=self.graphs is not None)
         for ph in self.phases:
             ph.start_event = ph.end_event = None
             if rank == 0 and device.type == 'cuda':
@@ -104,43 +108,70 @@ class Trainer:
         img, c = next(self._iterator)
         return img.to(self.device, non_blocking=True), c.to(self.device, non_blocking=True)
 
-    def run_iteration(self):
-        """One loop iteration (reference :277-337)."""
+    def _stage_inputs(self):
+        """This iteration's reals, labels and latents at FIXED addresses (a recorded phase reads them where they were when
+        it was recorded): drawn as upstream (:279-286), then copied into persistent tensors."""
         device, batch_gpu, ts = self.device, self.batch_gpu, self.training_set
         per_rank = self.batch_size // self.num_gpus
+        img, c = self._next_reals()
+        real_img = img.to(torch.float32) / 127.5 - 1
+        n = len(self.phases) * per_rank
+        if ts.label_dim > 0:
+            labels = np.stack([ts.get_label(np.random.randint(len(ts))) for _ in range(n)])
+            gen_c = torch.from_numpy(labels).pin_memory().to(device, non_blocking=True)
+        else:       # unconditional: empty labels, no host work (upstream draws len(phases)*batch numpy labels per iteration)
+            gen_c = None
+        if self._static is None:
+            st = self._static = dnnlib.EasyDict()
+            st.real_img, st.real_c = real_img.clone(), c.clone()
+            st.z = torch.empty([n, self.G.z_dim], device=device)
+            st.gen_c = gen_c.clone() if gen_c is not None else torch.zeros([n, 0], device=device)
+            st.img_rounds, st.c_rounds = st.real_img.split(batch_gpu), st.real_c.split(batch_gpu)
+            st.z_rounds = [z.split(batch_gpu) for z in st.z.split(per_rank)]
+            st.gen_c_rounds = [cc.split(batch_gpu) for cc in st.gen_c.split(per_rank)]
+        else:
+            st = self._static
+            st.real_img.copy_(real_img)
+            if c.numel():
+                st.real_c.copy_(c)
+            if gen_c is not None:
+                st.gen_c.copy_(gen_c)
+        st.z.normal_()
+        return st
+
+    def run_iteration(self):
+        """One loop iteration (reference :277-337)."""
+        device = self.device
         with torch.autograd.profiler.record_function('data_fetch'):
-            img, c = self._next_reals()
-            phase_real_img = (img.to(torch.float32) / 127.5 - 1).split(batch_gpu)
-            phase_real_c = c.split(batch_gpu)
-            all_gen_z = torch.randn([len(self.phases) * per_rank, self.G.z_dim], device=device)
-            all_gen_z = [z.split(batch_gpu) for z in all_gen_z.split(per_rank)]
-            if ts.label_dim > 0:
-                labels = np.stack([ts.get_label(np.random.randint(len(ts))) for _ in range(len(self.phases) * per_rank)])
-                all_gen_c = torch.from_numpy(labels).pin_memory().to(device)
-            else:       # unconditional: empty labels, no host work (upstream draws len(phases)*batch numpy labels per iteration)
-                all_gen_c = torch.zeros([len(self.phases) * per_rank, 0], device=device)
-            all_gen_c = [cc.split(batch_gpu) for cc in all_gen_c.split(per_rank)]
-        ran, rounds = 0, len(phase_real_img)
-        for phase, phase_gen_z, phase_gen_c in zip(self.phases, all_gen_z, all_gen_c):
+            st = self._stage_inputs()
+        ran, rounds = 0, len(st.img_rounds)
+        for phase, phase_gen_z, phase_gen_c in zip(self.phases, st.z_rounds, st.gen_c_rounds):
             if self.batch_idx % phase.interval != 0:
                 continue
             if phase.start_event is not None:
                 phase.start_event.record(torch.cuda.current_stream(device))
-            phase.begin()
-            for round_idx, (real_img, real_c, gen_z, gen_c) in enumerate(zip(phase_real_img, phase_real_c, phase_gen_z, phase_gen_c)):
-                self.loss.accumulate_gradients(phase=phase.name, real_img=real_img, real_c=real_c, gen_z=gen_z, gen_c=gen_c,
-                                               sync=(round_idx == rounds - 1), gain=phase.interval)
-            phase.finish(self.grad_sync)
+
+            def accumulate():
+                for round_idx, (real_img, real_c, gen_z, gen_c) in enumerate(zip(st.img_rounds, st.c_rounds, phase_gen_z, phase_gen_c)):
+                    self.loss.accumulate_gradients(phase=phase.name, real_img=real_img, real_c=real_c, gen_z=gen_z, gen_c=gen_c,
+                                                   sync=(round_idx == rounds - 1), gain=phase.interval)
+            phase_engine.run_phase(phase, accumulate, self.grad_sync, self.graphs, self.num_gpus)
             if phase.end_event is not None:
                 phase.end_event.record(torch.cuda.current_stream(device))
+                phase['_timed'] = True
             ran += 1
         with torch.autograd.profiler.record_function('Gema'):
-            phase_engine.update_ema(self.G_ema, self.G, phase_engine.ema_beta_for(self.batch_size, self.cur_nimg, self.ema_kimg, self.ema_rampup))
+            beta = phase_engine.ema_beta_for(self.batch_size, self.cur_nimg, self.ema_kimg, self.ema_rampup)
+            if self.graphs is not None and beta == getattr(self, '_ema_beta_prev', None):
+                self.graphs.run(('ema', beta), lambda: phase_engine.update_ema(self.G_ema, self.G, beta))
+            else:
+                phase_engine.update_ema(self.G_ema, self.G, beta)
+            self._ema_beta_prev = beta
         self.cur_nimg += self.batch_size
         self.batch_idx += 1
         if self.ada_stats is not None and self.batch_idx % self.ada_interval == 0:
             self.ada_stats.update()
-            adjust = np.sign(self.ada_stats['Loss/signs/real'] - self.ada_target) * (self.batch_size * self.ada_interval) / (self.ada_kimg * 1000)
+            adjust = phase_engine.ada_adjust(self.ada_stats['Loss/signs/real'], self.ada_target, self.batch_size, self.ada_interval, self.ada_kimg)
             self.augment_pipe.p.copy_((self.augment_pipe.p + adjust).max(misc.constant(0, device=device)))
         return ran
 
@@ -186,8 +217,12 @@ def training_loop(run_dir='.', training_set_kwargs={}, data_loader_kwargs={}, G_
             torch.save(dict(G=trainer.G.state_dict(), D=trainer.D.state_dict(), G_ema=trainer.G_ema.state_dict()),
                        os.path.join(run_dir, f'network-snapshot-{trainer.cur_nimg // 1000:06d}.pth'))
         for ph in trainer.phases:
-            if ph.start_event is not None and ph.end_event.query():
-                training_stats.report0('Timing/' + ph.name, ph.start_event.elapsed_time(ph.end_event))
+            # every rank registers every name (rank != 0 reports nothing under it): Collector._sync all-reduces one
+            # [n_names, 3] tensor, so the name tables must have the same length everywhere (reference :411-416)
+            value = []
+            if ph.start_event is not None and ph.get('_timed') and ph.end_event.query():
+                value = ph.start_event.elapsed_time(ph.end_event)
+            training_stats.report0('Timing/' + ph.name, value)
         stats_collector.update()
         if stats_jsonl is not None:
             stats_jsonl.write(json.dumps(dict(stats_collector.as_dict(), timestamp=time.time())) + '\n')

@@ -446,6 +446,148 @@ def gen_augment():
     save('augment', arrays, dict(cases=cases))
 
 
+def gen_aio():
+    """The global half of the all-in-one step (custom/loss_aio.py:182-341) and the STN end to end
+    (fukuwarai/networks.py:148-258), on toy networks whose weights are stored with the vectors:
+      * theta_constrain_loss: value and gradient;
+      * STNv2b / STNv2c forward: theta, re-placed layers, d/dx and d/dweights for a random upstream gradient;
+      * MontageGANLoss global_Gmain / global_Dmain / global_Dreg / global_Dboth / global_Gboth / global_Greg with the analytic
+        composite (renderer=None): every statistic the phase reports (count, sum, sum of squares) and the gradient
+        sum / abs-sum it leaves on every parameter of every module."""
+    from custom import loss_aio as LA
+    from custom import networks_aio as NA
+    from fukuwarai import networks as FN
+    from torch_utils import training_stats as TS
+    arrays, cases = {}, []
+    g = torch.Generator().manual_seed(4242)
+
+    # (1) theta constraint
+    theta = torch.eye(2, 3).repeat(3, 4, 1, 1)
+    theta[..., 2] = torch.randn([3, 4, 2], generator=g) * 1.2          # some translations outside [-1, 1]
+    th = theta.clone().requires_grad_(True)
+    val = LA.theta_constrain_loss(th, torch.device('cpu'))
+    dth, = torch.autograd.grad([val], [th])
+    arrays['tc_theta'], arrays['tc_value'], arrays['tc_grad'] = theta, val.detach(), dth
+    cases.append(dict(id=0, op='theta_constrain_loss'))
+
+    # (2) STN end to end at 128x128 (the smallest size its five conv/pool stages accept), tiny widths
+    for ci, (cls, lo) in enumerate((('STNv2b', 0.0), ('STNv2c', -1.0))):
+        torch.manual_seed(50 + ci)
+        stn = getattr(FN, cls)(img_resolution=128, img_channels=4, img_layers=3, nf1=4, nf2=8)
+        with torch.no_grad():
+            stn.fc_loc[2].weight.normal_(0, 0.5)
+            stn.fc_loc[2].bias.normal_(0, 0.2)
+        _sd(f'stn{ci}', stn, arrays)
+        x = torch.rand([2, 3, 4, 16, 16], generator=g).repeat_interleave(8, 3).repeat_interleave(8, 4)      # blocky: compresses well
+        x = (x * (1 - lo) + lo).contiguous()
+        xr = x.clone().requires_grad_(True)
+        y, th = stn(xr)
+        dy = torch.randn([2, 3, 4, 16, 16], generator=g).repeat_interleave(8, 3).repeat_interleave(8, 4).contiguous()
+        params = list(stn.parameters())
+        grads = torch.autograd.grad([y], [xr] + params, [dy])
+        arrays[f'stn{ci}_x16'], arrays[f'stn{ci}_dy16'] = x[..., ::8, ::8], dy[..., ::8, ::8]
+        arrays[f'stn{ci}_theta'], arrays[f'stn{ci}_y'], arrays[f'stn{ci}_dx'] = th.detach(), y.detach().to(torch.float16), grads[0].to(torch.float16)
+        arrays[f'stn{ci}_y_sum'], arrays[f'stn{ci}_dx_sum'] = y.detach().double().sum(), grads[0].double().sum()
+        arrays[f'stn{ci}_dparam_sum'] = np.asarray([float(t.double().sum()) for t in grads[1:]])
+        arrays[f'stn{ci}_dparam_abs'] = np.asarray([float(t.double().abs().sum()) for t in grads[1:]])
+        cases.append(dict(id=1 + ci, op='stn', cls=cls, names=[n for n, _ in stn.named_parameters()]))
+
+    # (3) the global phases of MontageGANLoss
+    torch.manual_seed(808)
+    L, names = 2, ['hair', 'face_skin']
+    sk = dict(w_dim=16, img_resolution=32, img_channels=4, init_res=[8, 8], conv_config_index=3, channel_base=128,
+              channel_max=8, num_fp16_res=0, conv_clamp=256)
+    dk = dict(img_channels=4, init_res=[8, 8], conv_config_index=3, channel_base=128, channel_max=8, num_fp16_res=0,
+              conv_clamp=256, epilogue_kwargs=dict(mbstd_group_size=2))
+    S = [NA.SynthesisNetwork(**sk) for _ in range(L)]
+    M = NA.GlobalMappingNetwork(z_dim=16, w_dim=16, c_dim=0, num_ws=S[0].num_ws, num_splits=L, num_layers=2)
+    DL = [NA.Discriminator(img_resolution=32, **dk) for _ in range(L)]
+    GD = NA.Discriminator(img_resolution=256, **dict(dk, channel_base=1024, channel_max=4))
+    STN = FN.STNv2c(img_resolution=256, img_channels=4, img_layers=L, nf1=2, nf2=4)
+    with torch.no_grad():
+        STN.fc_loc[2].weight.normal_(0, 0.8)            # push some translations over the +-1 box: theta loss non-zero
+        STN.fc_loc[2].bias.normal_(0, 0.9)
+        for m in S:
+            for n_, p_ in m.named_parameters():
+                if n_.endswith('noise_strength'):
+                    p_.fill_(0.2)
+    mods = dict(M=M, S0=S[0], S1=S[1], GD=GD, STN=STN)
+    for k, m in mods.items():
+        _sd(f'aio.{k}', m, arrays)
+    for m in list(mods.values()) + DL:
+        m.train().requires_grad_(False)
+    real16 = torch.rand([2, L, 4, 16, 16], generator=g)
+    real16[:, :, 3] = (real16[:, :, 3] > 0.5).float()
+    arrays['aio_real16'] = real16
+    real = (real16.repeat_interleave(16, 3).repeat_interleave(16, 4) * 2 - 1).contiguous()         # [B,L,4,256,256] in [-1,1]
+    sd0 = {k: {n: v.clone() for n, v in m.state_dict().items()} for k, m in mods.items()}
+    runs = [(phase, False) for phase in ['global_Gmain', 'global_Greg', 'global_Dmain', 'global_Dreg', 'global_Gboth', 'global_Dboth']]
+    # deterministic variants (no style mixing, noise strength 0): comparable on a device whose generator differs
+    runs += [(phase, True) for phase in ['global_Gmain', 'global_Dmain', 'global_Dreg']]
+    for pi, (phase, det) in enumerate(runs):
+        for k, m in mods.items():
+            m.load_state_dict(sd0[k])
+            for p_ in m.parameters():
+                p_.grad = None
+        if det:
+            with torch.no_grad():
+                for m in S:
+                    for n_, p_ in m.named_parameters():
+                        if n_.endswith('noise_strength'):
+                            p_.zero_()
+        on = [M, *S, STN] if phase[7] == 'G' else [GD]
+        for m in on:
+            m.requires_grad_(True)
+        TS._counters.clear()
+        loss = LA.MontageGANLoss(device=torch.device('cpu'), global_d_real_use_renderer=False, renderer_retrain_use_real=False,
+                                 mapping_network=M, layer_names=names, local_G_list=S, augment_pipe_list=[None] * L,
+                                 local_D_list=DL, pos_estimator=STN, renderer=None, global_augment_pipe=None, global_D=GD,
+                                 global_r1_gamma=10, style_mixing_prob=0 if det else 0.9, r1_gamma=10)
+        torch.manual_seed(3000 + pi)
+        gen_z = torch.randn([2, 16])
+        arrays[f'g{pi}_gen_z'] = gen_z
+        loss.accumulate_gradients(phase=phase, real_blchw=real, real_list_of_bchw=None, gen_z=gen_z, sync=True, gain=1.5)
+        for m in on:
+            m.requires_grad_(False)
+        gnames, sums, abss = [], [], []
+        for k, m in mods.items():
+            for n_, p_ in m.named_parameters():
+                if p_.grad is not None:
+                    gnames.append(f'{k}.{n_}'); sums.append(float(p_.grad.double().sum())); abss.append(float(p_.grad.double().abs().sum()))
+        arrays[f'g{pi}_grad_sum'], arrays[f'g{pi}_grad_abs'] = np.asarray(sums), np.asarray(abss)
+        snames = sorted(TS._counters)
+        arrays[f'g{pi}_stats'] = np.asarray([sum(TS._counters[n_].values()).numpy() for n_ in snames]).reshape(len(snames), 3)
+        cases.append(dict(id=3 + pi, op='global_phase', phase=phase, seed=3000 + pi, gain=1.5, deterministic=det, grad_names=gnames, stat_names=snames))
+    cases.append(dict(id=99, op='aio_config', S_kwargs=sk, D_kwargs=dk, layer_names=names))
+    save('aio', arrays, dict(cases=cases))
+
+
+def gen_renderer():
+    """The two renderer checkpoints the reference ships (pretrained/diff_rendering/*/renderer032000.pth.tar; loaded with
+    weights_only=True): key names, shapes and float64 checksums of every tensor, and the output of the reference's own
+    RendererTanh / RendererSubPixelConv (diff_rendering/networks.py:6-134) with those weights on a seeded input."""
+    from diff_rendering import networks as RN
+    arrays, cases = {}, []
+    g = torch.Generator().manual_seed(606)
+    x16 = torch.rand([1, 9, 4, 16, 16], generator=g) * 2 - 1
+    arrays['x16'] = x16
+    x = x16.repeat_interleave(4, 3).repeat_interleave(4, 4).contiguous()            # [1,9,4,64,64]
+    for i, (sub, cls) in enumerate((('211120-1956-output-tanh', 'RendererTanh'), ('211210-1834-output-subpixel', 'RendererSubPixelConv'))):
+        path = f'/root/reference/pretrained/diff_rendering/{sub}/renderer032000.pth.tar'
+        saved = torch.load(path, map_location='cpu', weights_only=True)
+        sd = saved['renderer']
+        net = getattr(RN, cls)(img_resolution=256, img_channels=4, img_layers=9)
+        net.load_state_dict(sd, strict=True)
+        net.eval()
+        with torch.no_grad():
+            y = net(x)
+        arrays[f'r{i}_y'] = y
+        cases.append(dict(id=i, cls=cls, path=f'pretrained/diff_rendering/{sub}/renderer032000.pth.tar', global_step=int(saved['global_step']),
+                          keys=list(sd.keys()), shapes=[list(v.shape) for v in sd.values()],
+                          sums=[float(v.double().sum()) for v in sd.values()]))
+    save('renderer', arrays, dict(cases=cases))
+
+
 def gen_warp():
     """ADA's resampling step and colour matrix through the reference's own calls:
     F.affine_grid + torch_utils.ops.grid_sample_gradfix.grid_sample (training/augment.py:376-377) and
@@ -490,6 +632,6 @@ def gen_warp():
 if __name__ == '__main__':
     _import_reference()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv', 'montage', 'nets', 'augment', 'warp']
+    which = sys.argv[1:] or ['upfirdn2d', 'bias_act', 'conv', 'montage', 'nets', 'augment', 'warp', 'aio', 'renderer']
     for w in which:
         globals()['gen_' + w]()

@@ -59,21 +59,38 @@ def test_augment_pipe_matches_reference():
     assert n == 30
 
 
-def test_layout_glue_matches_reference():
+def _layout_glue(device):
     IU = mod('custom_utils.image_utils')
     cases, arr = load_golden('augment')
     c = [c for c in cases if c['op'] == 'layout'][0]
-    lay = T(arr['lay']).float() / 255
+    lay = (T(arr['lay']).float() / 255).to(device)
     pf = IU.generate_pseudo_fake(lay)
-    assert np.array_equal((pf * 255).round().to(torch.uint8).numpy(), arr['pseudo_fake_u8'])
+    assert np.array_equal((pf * 255).round().to(torch.uint8).cpu().numpy(), arr['pseudo_fake_u8'])
     outs = IU.make_batch_for_local_d(lay, c['sizes'], to_minus11=True)
     for k, o in enumerate(outs):
-        np.testing.assert_allclose(o.numpy(), arr[f'local_d_{k}'], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(o.cpu().numpy(), arr[f'local_d_{k}'], rtol=0, atol=1e-7)
     # single-image helpers agree with the batched path
     crop = IU.crop_to_content(lay[0, 0])
     assert crop.shape == (4, 29, 59)            # the max row/column is excluded, as upstream
-    np.testing.assert_allclose(IU.pad_256(crop).numpy(), pf[0, 0].numpy(), atol=0)
+    np.testing.assert_allclose(IU.pad_256(crop).cpu().numpy(), pf[0, 0].cpu().numpy(), atol=0)
     assert IU.crop_to_content(lay[1, 1]).shape == (4, 0, 0)        # empty layer
+    # make_batch_for_pos_estimator / pad_256 (image_utils.py:216-243) against the reference's stack
+    _, marr = load_golden('montage')
+    pe = IU.make_batch_for_pos_estimator([T(marr['pe_in0']).to(device), T(marr['pe_in1']).to(device)], pad_value=-1)
+    assert list(pe.shape) == list(marr['pe_out_shape'])
+    np.testing.assert_allclose(pe[:, :, :, 112:144, 112:144].cpu().numpy(), marr['pe_out_corner'], atol=0)
+    np.testing.assert_allclose(float(pe.double().sum()), float(marr['pe_out_sum']), rtol=1e-12)
+
+
+def test_layout_glue_matches_reference():
+    _layout_glue('cpu')
+
+
+@pytest.mark.gpu
+def test_layout_glue_matches_reference_on_gpu():
+    """The batched device gathers of generate_pseudo_fake / make_batch_for_local_d / make_batch_for_pos_estimator on the
+    MI355X, bit-for-bit against the reference's per-sample python loops (no host synchronisation in the batched path)."""
+    _layout_glue('cuda:0')
 
 
 def test_fixed_margin_mode_gives_the_same_images():

@@ -33,16 +33,25 @@ def _grad_sync_worker(rank, world, init_file, out_dir):
     params[2].grad[0, 0] = float('inf')                                # +inf -> 1e5
     params[3].grad = None if rank == 1 else params[3].grad            # a parameter one rank did not touch
     sync = PE.GradSync(world_size=world)
-    sync(params)
-    assert not sync._agreed                                            # a disagreement is never cached: it is re-checked every time
+    sync(params, key='opt')
+    assert sync._verified['opt'] == 1                                  # whether a check runs depends on the call COUNT only (same on all ranks)
     torch.save([p.grad.clone() for p in params], os.path.join(out_dir, f'g{rank}.pt'))
-    # second round: every rank has every gradient -> the signature is verified once, then trusted (no read-back per phase)
+    flat = sync._flat['opt']
+    assert all(p.grad.data_ptr() >= flat.data_ptr() and p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4 for p in params)   # grads are slices of the arena
+    # later rounds: every rank has every gradient; verified VERIFY_FIRST times in total, then trusted (no read-back per phase)
+    for _ in range(3):
+        for i, p in enumerate(params):
+            p.grad = torch.full_like(p, float(rank + 1))
+        sync(params, key='opt')
+        assert sync._flat['opt'] is flat                               # persistent: no flatten allocation per phase
+        assert all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in params)     # mean(1, 2)
+    assert sync._verified['opt'] == PE.GradSync.VERIFY_FIRST
+    # bf16 on the wire: same mean up to bf16 rounding of the summands
+    sync16 = PE.GradSync(world_size=world, wire_dtype=torch.bfloat16)
     for i, p in enumerate(params):
-        p.grad = torch.full_like(p, float(rank + 1))
-    sync(params)
-    assert len(sync._agreed) == 1
-    sync(params)
-    assert len(sync._agreed) == 1 and all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in params)     # mean(1.5, 1.5): the second call reduced again
+        p.grad = torch.full_like(p, float(rank + 1) * 0.3)
+    sync16(params, key='opt')
+    assert all(torch.allclose(p.grad, torch.full_like(p, 0.45), rtol=1e-2) for p in params)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -59,10 +68,14 @@ def test_grad_sync_mean_nan_scrub_and_missing_grads():
     assert torch.allclose(g0[3], torch.full_like(g0[3], 2.0))         # ranks disagreed on who has a gradient -> union, (4 + 0) / 2
 
 
-def _trainer_worker(rank, world, init_file, out_dir):
+def _tick_worker(rank, world, init_file, out_dir):
+    """What train_aio.py's subprocess_fn does for num_gpus > 1 (reference train_aio.py:404-426): init_process_group,
+    training_stats.init_multiprocessing, then the loop through its first ticks -- the statistics all-reduce needs every
+    rank to hold the same name table (rank 0 alone times the phases)."""
     _init(rank, world, init_file)
     TL = importlib.import_module(f'{PKG}.custom.training_loop_aio')
-    misc = importlib.import_module(f'{PKG}.torch_utils.misc')
+    TS = importlib.import_module(f'{PKG}.torch_utils.training_stats')
+    TS.init_multiprocessing(rank=rank, sync_device=torch.device('cpu'))
     kw = TL.default_kwargs(num_gpus=world, batch_gpu=2, num_fp16_res=0)
     for k in ('local_G_kwargs', 'local_D_kwargs', 'global_D_kwargs'):
         kw[k].channel_base, kw[k].channel_max = 1024, 8
@@ -70,22 +83,32 @@ def _trainer_worker(rank, world, init_file, out_dir):
     kw.local_G_kwargs.w_dim = 16
     kw.training_set_kwargs.update(num_layers=2, num_samples=16)
     kw.data_loader_kwargs = dict(num_workers=0)
-    torch.manual_seed(100 + rank)                                       # different initial weights per rank ...
-    t = TL.AioTrainer(rank=rank, device='cpu', cfg=dict(TL.config, bypass_renderer=True), **kw)
-    w0 = t.local_D_list[0].b256.conv0.weight.detach().clone()
-    ran = t.run_iteration()
+    for k in ('num_gpus', 'batch_gpu', 'batch_size'):
+        kw.pop(k)
+    old = dict(TL.config)
+    TL.config['bypass_renderer'] = True
+    misc = importlib.import_module(f'{PKG}.torch_utils.misc')
+    try:
+        t = TL.training_loop(rank=rank, num_gpus=world, batch_size=2 * world, batch_gpu=2, run_dir=os.path.join(out_dir, 'run'),
+                             total_kimg=2 * world / 1000, kimg_per_tick=2 * world / 1000, network_snapshot_ticks=None, device='cpu',
+                             random_seed=100 + rank, **kw)
+    finally:
+        TL.config.update(old)
     for m in [t.mapping_network, *t.local_G_list, *t.local_D_list, t.pos_estimator, t.global_D]:
-        misc.check_ddp_consistency(m, ignore_regex=r'.*\.w_avg')       # ... yet identical after broadcast + synced steps
-    torch.save(dict(ran=ran, moved=not torch.equal(w0, t.local_D_list[0].b256.conv0.weight.detach()),
-                    w=t.local_D_list[0].b256.conv0.weight.detach().clone(), z_seed=rank), os.path.join(out_dir, f't{rank}.pt'))
+        misc.check_ddp_consistency(m, ignore_regex=r'.*\.w_avg')       # different seeds per rank, yet identical after broadcast + synced steps
+    names = sorted(n for n in TS._counters if n.startswith('Timing/'))
+    torch.save(dict(names=names, n_names=len(TS._counters), nimg=t.cur_nimg, w=t.local_D_list[0].b256.conv0.weight.detach().clone(),
+                    flat=sorted(v.numel() for v in t.grad_sync._flat.values())), os.path.join(out_dir, f'k{rank}.pt'))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_aio_iteration_two_ranks_stay_consistent():
+def test_two_rank_loop_ticks_with_synchronised_statistics():
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_trainer_worker, args=(2, os.path.join(d, 'init'), d), nprocs=2, join=True)
-        r0, r1 = torch.load(os.path.join(d, 't0.pt')), torch.load(os.path.join(d, 't1.pt'))
-    assert r0['ran'] == r1['ran'] == 12          # 2 x (Gmain, Greg, Dmain, Dreg) + 4 global phases
-    assert r0['moved'] and r1['moved']
+        mp.spawn(_tick_worker, args=(2, os.path.join(d, 'init'), d), nprocs=2, join=True)
+        r0, r1 = torch.load(os.path.join(d, 'k0.pt')), torch.load(os.path.join(d, 'k1.pt'))
+        assert os.path.exists(os.path.join(d, 'run', 'stats.jsonl'))
+    assert r0['names'] == r1['names'] and len(r0['names']) == 12 and r0['n_names'] == r1['n_names']      # 2 x 4 local + 4 global phases
+    assert r0['nimg'] == r1['nimg'] == 4
     assert torch.equal(r0['w'], r1['w'])
+    assert r0['flat'] == r1['flat'] and len(r0['flat']) == 6          # one persistent gradient buffer per optimizer: 2 x (G, D) + global G, D

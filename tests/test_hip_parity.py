@@ -439,6 +439,38 @@ def test_bias_act_unaligned_and_empty(native, oracle):
         plugin.bias_act(torch.zeros([2, 3], device=DEV), torch.zeros([4], device=DEV), null, null, null, 0, 1, 1, 0.0, 1.0, -1.0)
 
 
+@pytest.mark.parametrize('act,gain,clamp', [('linear', 0.7, 0.5), ('linear', 1.0, 0.5), ('linear', 0.7, None), ('lrelu', 0.7, 0.5), ('relu', None, None)])
+@pytest.mark.parametrize('memfmt', ['contiguous', 'channels_last'])
+def test_bias_act_plain_backward_matches_ref_impl(native, act, gain, clamp, memfmt):
+    """``.backward()`` WITHOUT create_graph (the one-pass fused backward kernel where it applies, the gradient kernel
+    otherwise) against impl='ref' -- in particular act='linear' with gain != 1, which saves no output to evaluate the
+    gain against and therefore must not take the fused path."""
+    B = op('bias_act')
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn([3, 8, 10, 12], device=DEV, generator=g)
+    if memfmt == 'channels_last':
+        x = x.contiguous(memory_format=torch.channels_last)
+    b = torch.randn([8], device=DEV, generator=g)
+    dy = torch.randn([3, 8, 10, 12], device=DEV, generator=g)
+    res = []
+    for impl in ('cuda', 'ref'):
+        xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = B.bias_act(xr, br, act=act, gain=gain, clamp=clamp, impl=impl)
+        y.backward(dy)
+        res.append((y.detach(), xr.grad, br.grad))
+    (y0, dx0, db0), (y1, dx1, db1) = res
+    np.testing.assert_allclose(y0.cpu().numpy(), y1.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # 'linear' saves neither input nor output (spec.ref == ''), so its native gradient cannot zero the saturated elements
+    # the way aten's clamp does -- upstream's CUDA path behaves the same (bias_act.cu:139-141 reads yref = 0): compare the
+    # unsaturated elements there, everything otherwise
+    free = torch.ones_like(y0, dtype=torch.bool) if (act != 'linear' or clamp is None) else (y0.abs() < clamp)
+    np.testing.assert_allclose(dx0[free].cpu().numpy(), dx1[free].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    if bool(free.all()):
+        np.testing.assert_allclose(db0.cpu().numpy(), db1.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    else:
+        np.testing.assert_allclose(dx0[~free].cpu().numpy(), (dy * (gain or 1.0))[~free].cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 def test_bias_act_full_size_properties(native):
     B = op('bias_act')
     g = torch.Generator(device=DEV).manual_seed(1)
@@ -456,14 +488,18 @@ def test_bias_act_full_size_properties(native):
 # conv2d_resample / modulated conv building blocks on the GPU (aten convs + native resampling)
 
 @pytest.mark.parametrize('gradfix', [False, True])
-def test_conv2d_resample_golden_on_gpu(native, gradfix):
+def test_conv2d_resample_and_modulated_conv2d_golden_on_gpu(native, gradfix):
+    """All 26 reference vectors of tests/golden/conv.npz on the device: the six conv2d_resample paths, the 16
+    modulated_conv2d cases (fused / non-fused, demodulation, noise, up 1/2: y, dx, dw, dstyles) and fma."""
     cases, arr = load_golden('conv')
+    before = native.launch_counts()
     for c in cases:
         out = run_conv_case(c, arr, device=DEV, gradfix=gradfix)
-        if out is None:
-            continue
+        assert out is not None, c
         for k, v in out.items():
             np.testing.assert_allclose(v.detach().cpu().numpy(), arr[f'c{c["id"]}_{k}'], rtol=1e-3, atol=1e-3, err_msg=f'{c} {k}')
+    after = native.launch_counts()
+    assert after['demod'] > before['demod']        # the native demodulation coefficients were part of it
 
 
 # --------------------------------------------------------------------------------------------

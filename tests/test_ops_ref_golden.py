@@ -119,23 +119,32 @@ def run_conv_case(c, arr, device='cpu', gradfix=False):
             y = FMA.fma(a, b, cc)
             da, db, dc = torch.autograd.grad([y], [a, b, cc], [T(arr[f'c{i}_dy']).to(device)])
             return dict(y=y, da=da, db=db, dc=dc)
+        if c['op'] == 'modulated_conv2d':
+            # training/networks.py:37-98 of the reference: fused (grouped conv, per-sample weights) and non-fused
+            # (scale -> shared conv -> fma) forms, demodulation on/off, noise on/off, up 1/2
+            NW = importlib.import_module(f'{PKG}.training.networks')
+            x, w, s = (T(arr[f'c{i}_{k}']).to(device).requires_grad_(True) for k in 'xws')
+            nz = T(arr[f'c{i}_noise']).to(device) if c['noise'] else None
+            y = NW.modulated_conv2d(x=x, weight=w, styles=s, noise=nz, up=c['up'], padding=1, resample_filter=f,
+                                    demodulate=c['demodulate'], flip_weight=(c['up'] == 1), fused_modconv=c['fused'])
+            dx, dw, ds = torch.autograd.grad([y], [x, w, s], [T(arr[f'c{i}_dy']).to(device)])
+            return dict(y=y, dx=dx, dw=dw, ds=ds)
     finally:
         G.enabled = old
     return None
 
 
 @pytest.mark.parametrize('gradfix', [False, True])
-def test_conv2d_resample_and_fma_match_reference(gradfix):
+def test_conv2d_resample_modulated_conv2d_and_fma_match_reference(gradfix):
     cases, arr = load_golden('conv')
     n = 0
     for c in cases:
         out = run_conv_case(c, arr, gradfix=gradfix)
-        if out is None:
-            continue
+        assert out is not None, c               # every committed vector is in force
         n += 1
         for k, v in out.items():
             np.testing.assert_allclose(v.detach().numpy(), arr[f'c{c["id"]}_{k}'], rtol=2e-4, atol=2e-4, err_msg=f'{c} {k}')
-    assert n == 10
+    assert n == 26          # 9 conv2d_resample + 16 modulated_conv2d + 1 fma
 
 
 def test_conv2d_gradfix_double_backward_and_no_weight_gradients():

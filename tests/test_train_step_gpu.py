@@ -255,3 +255,99 @@ def test_augment_pipe_on_gpu_matches_reference_golden():
     finally:
         AU.fixed_margin = AU.side_stream_margin = False
         GS.enabled = False
+
+
+def _tiny_aio(graphs, ada, seed=3, **extra):
+    TL, DS = mod('custom.training_loop_aio'), mod('custom.dataset_aio')
+    kw = TL.default_kwargs(num_gpus=1, batch_gpu=2, num_fp16_res=2, fp16_dtype=torch.bfloat16)
+    for k in ('local_G_kwargs', 'local_D_kwargs', 'global_D_kwargs'):
+        kw[k].channel_base, kw[k].channel_max = 256, 16
+    kw.mapping_kwargs.num_layers = 2
+    kw.training_set_kwargs.num_layers = 2
+    if ada:
+        AU = mod('training.augment')
+        kw.augment_kwargs = dict(class_name='training.augment.AugmentPipe', **AU.augpipe_specs['bgc'])
+        kw.augment_p = 0.4
+    reals = [DS.synthetic_layers(2, 2, 256, seed=5 + i, device=DEV) for i in range(2)]
+    return TL.AioTrainer(device=DEV, cfg=dict(TL.config, bypass_renderer=True), resident_batches=reals, random_seed=seed,
+                         graphs=graphs, graph_warmup=1, **kw, **extra)
+
+
+def test_recorded_function_consumes_the_generator_like_eager_code():
+    """PhaseGraphs.run: replays draw the SAME random numbers an eager execution would have drawn at that point (the
+    philox offset advances per replay), and in-place state updates made by the recorded kernels persist."""
+    PE = mod('training.phase_engine')
+    outs = []
+    for use_graph in (False, True):
+        torch.manual_seed(1234)
+        graphs = PE.PhaseGraphs(DEV, warmup=1) if use_graph else None
+        state = torch.zeros([], device=DEV)
+        buf = torch.empty([5, 1000], device=DEV)
+        i_dev = torch.zeros([], dtype=torch.int64, device=DEV)
+
+        def body():
+            r = torch.randn([1000], device=DEV) + torch.rand([1000], device=DEV)
+            state.add_(r.sum())
+            buf.index_copy_(0, i_dev.reshape(1), r.reshape(1, -1))
+            i_dev.add_(1)
+        replayed = []
+        for _ in range(5):
+            if graphs is None:
+                body()
+            else:
+                replayed.append(graphs.run('body', body))
+        torch.cuda.synchronize()
+        if use_graph:
+            assert replayed == [False, True, True, True, True] and graphs.captured == 1
+        outs.append((buf.clone(), state.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert len(torch.unique(outs[0][0][:, 0])) == 5            # five different draws, not one replayed five times
+
+
+@pytest.mark.parametrize('ada', [False, True])
+def test_recorded_phases_equal_the_eager_loop(ada):
+    """phase_engine.PhaseGraphs: the same tiny train_aio run eagerly (twice: the run-to-run spread that float atomics in
+    MIOpen's split-K and the fused reductions cause) and with every phase recorded into a HIP graph after one eager
+    execution.  All consume the device generator in the same order, so the recorded run must sit within that spread."""
+    AU = mod('training.augment')
+    TS = mod('torch_utils.training_stats')
+    AU.fixed_margin, AU.side_stream_margin = True, False
+    try:
+        out = []
+        for graphs in (False, False, True):
+            torch.manual_seed(11)
+            TS._counters.clear()
+            t = _tiny_aio(graphs, ada)
+            t.run_iteration()
+            t.run_iteration()               # graphs: every phase was recorded after its eager run above; the main phases replay here
+            torch.cuda.synchronize()
+            g_first = [p.grad.detach().float().clone() for p in t.global_D.parameters()]      # gradients of the last phase (global_Dmain)
+            for _ in range(4):
+                t.run_iteration()
+            torch.cuda.synchronize()
+            if graphs:
+                assert t.graphs.captured >= 2 * 4 + 3 + 1 and t.graphs.replays >= 5 * (2 * 2 + 2)
+                assert 'global_Greg' not in t.graphs._graphs and 'global_Gmain' in t.graphs._graphs
+            w = [p.detach().float().clone() for m in [t.mapping_network, *t.local_G_list, *t.local_D_list, t.pos_estimator, t.global_D]
+                 for p in m.parameters()]
+            ema = [p.detach().float().clone() for p in t.global_G_ema['local_G_list'][0].parameters()]
+            stats = {k: sum(v.values()).clone() for k, v in TS._counters.items() if v}
+            out.append((w, ema, stats, g_first))
+            del t
+
+        def dist(xs, ys):
+            num = sum(float((a - b).square().sum()) for a, b in zip(xs, ys)) ** 0.5
+            return num / max(sum(float(a.square().sum()) for a in xs) ** 0.5, 1e-30)
+        (w0, e0, s0, g0), (w1, e1, s1, g1), (w2, e2, s2, g2) = out
+        assert len(w0) == len(w2) and len(g0) == len(g2)
+        # Adam with beta1 = 0 moves every weight by +-lr whatever the gradient's size, so rounding noise on near-zero
+        # gradients is amplified between iterations: the eager-vs-eager spread is the yardstick, a wrong replay (stale
+        # inputs, different random draws, a skipped optimizer step) lands far outside it
+        for name, a, b, c in (('first replayed gradients', g0, g1, g2), ('weights', w0, w1, w2), ('ema weights', e0, e1, e2)):
+            spread, got = dist(a, b), dist(a, c)
+            assert got <= 3 * spread + 2e-3, (name, got, spread)
+        assert set(s0) == set(s2)
+        for k in s0:
+            assert float(s0[k][0]) == float(s2[k][0]), k              # same number of reported elements
+    finally:
+        AU.fixed_margin = AU.side_stream_margin = False
