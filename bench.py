@@ -28,6 +28,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 PKG = 'docker-montage-gan_amd'
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS_16 = 2500.0        # MI355X_MICROARCH.md: bf16 / fp16 MFMA, dense
+MFMA_PEAK_TFLOPS_F32 = 157.3        # MI355X_MICROARCH.md: fp32 matrix (= vector) rate
 
 
 def mod(name):
@@ -87,10 +89,11 @@ def build_trainer(args, device, rank, world):
 
 
 def cpu_baseline(args):
-    """The same network/loss code on the host with the aten reference ops (impl='ref' because the tensors are
-    on the CPU): ONE local GAN's Gmain + Dmain phases at a small batch.  The full step also runs Greg/Dreg and,
-    for aio, the other L-1 local GANs and the global GAN; the sample is scaled by L only, so the reported CPU
-    rate is an UPPER bound."""
+    """The same network/loss code on the host with the aten reference ops (impl='ref' because the tensors are on the
+    CPU), SURVEY 8d: ONE local GAN's four phases at a small batch, weighted by their frequencies (Gmain + Dmain every
+    step, Greg every 4th, Dreg every 16th), scaled by the L layers of the aio step (the global GAN's phases are not run:
+    the reported CPU rate is an UPPER bound); plus BASELINE configs[0] (64x64, 1 layer, batch 4) as whole iterations of
+    ``training.training_loop.Trainer``."""
     NW, LS = mod('training.networks'), mod('training.loss')
     # the GPU box gives one GPU a share of 16 host cores: never oversubscribe it
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -109,38 +112,66 @@ def cpu_baseline(args):
     real = torch.randn([b, 4, args.res, args.res])
     c0 = torch.zeros([b, 0])
 
-    def one():
-        for phase, mods in (('Gmain', [M, S]), ('Dmain', [D])):
-            for m in mods:
-                m.requires_grad_(True)
-            loss.accumulate_gradients(phase=phase, real_img=real, gen_z=torch.randn([b, 512]), sync=True, gain=1, real_c=c0, gen_c=c0)
-            for m in mods:
-                m.requires_grad_(False)
-                for p in m.parameters():
-                    p.grad = None
+    def one(phase):
+        mods = [M, S] if phase[0] == 'G' else [D]
+        for m in mods:
+            m.requires_grad_(True)
+        t0 = time.time()
+        loss.accumulate_gradients(phase=phase, real_img=real, gen_z=torch.randn([b, 512]), sync=True, gain=1, real_c=c0, gen_c=c0)
+        dt = time.time() - t0
+        for m in mods:
+            m.requires_grad_(False)
+            for p in m.parameters():
+                p.grad = None
+        return dt
     print(f'[bench] cpu_baseline: {threads} threads, batch {b} ...', file=sys.stderr, flush=True)
     t_w = time.time()
-    one()                                   # warm-up
+    one('Gmain')                             # warm-up
     print(f'[bench] cpu_baseline warm-up {time.time() - t_w:.1f} s', file=sys.stderr, flush=True)
     t0 = time.time()
-    reps = 0
-    while reps < 1 or (time.time() - t0 < args.cpu_seconds and reps < 8):
-        one()
-        reps += 1
-    dt = (time.time() - t0) / reps
+    times = {ph: [] for ph in ('Gmain', 'Dmain', 'Greg', 'Dreg')}
+    while time.time() - t0 < args.cpu_seconds and len(times['Dreg']) < 4:
+        for ph in times:
+            times[ph].append(one(ph))
+    avg = {ph: sum(v) / len(v) for ph, v in times.items()}
+    dt = avg['Gmain'] + avg['Dmain'] + avg['Greg'] / 4 + avg['Dreg'] / 16          # one step of one local GAN
     layers = args.layers if args.workload == 'aio' else 1
-    return dict(value=round(b / (dt * layers), 4), unit='img/s', cores=threads, kind='port',
-                sample=(f'1 local GAN, phases Gmain+Dmain only, batch {b}, {args.res}x{args.res} fp32, {reps} repetition(s) of '
-                        f'{dt:.1f} s, scaled by {layers} layer(s); Greg/Dreg/global phases not run => upper bound of the CPU rate'))
+    out = dict(value=round(b / (dt * layers), 4), unit='img/s', cores=threads, kind='port',
+               sample=(f'1 local GAN, all four phases at their frequencies (Gmain {avg["Gmain"]:.2f} s + Dmain {avg["Dmain"]:.2f} s + Greg {avg["Greg"]:.2f} s / 4 '
+                       f'+ Dreg {avg["Dreg"]:.2f} s / 16), batch {b}, {args.res}x{args.res} fp32, {len(times["Dreg"])} repetition(s), scaled by {layers} layer(s); '
+                       f'the global GAN phases are not run => upper bound of the CPU rate'))
+    # BASELINE configs[0]: 64x64, 1 RGBA layer, batch 4, whole iterations of the base loop on the CPU
+    try:
+        TL = mod('training.training_loop')
+        kw = TL.default_kwargs(num_gpus=1, batch_gpu=4, resolution=64, num_fp16_res=0)
+        kw.training_set_kwargs.num_samples = 64
+        kw.data_loader_kwargs = dict(num_workers=0)
+        if args.tiny:
+            kw.G_kwargs.synthesis_kwargs.update(channel_base=512, channel_max=32)
+            kw.D_kwargs.update(channel_base=512, channel_max=32)
+        t1 = TL.Trainer(device='cpu', random_seed=0, **kw)
+        t1.run_iteration()                  # iteration 0: all four phases (warm-up)
+        t0 = time.time()
+        n = 0
+        while n < 4 and (n == 0 or time.time() - t0 < args.cpu_seconds / 2):
+            t1.run_iteration()              # iterations 1..4: Gmain + Dmain (+ Greg at the 4th)
+            n += 1
+        out['config1'] = dict(value=round(4 * n / (time.time() - t0), 3), unit='img/s',
+                              sample=f'BASELINE configs[0]: training_loop.Trainer, 64x64 RGBA, batch 4, fp32, {n} iteration(s) after the first, CPU aten impl=ref ops')
+    except Exception as e:          # the headline does not depend on it
+        out['config1'] = dict(error=repr(e))
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=16)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=32, help='timed iterations (32 = two lazy-regularisation periods, SURVEY 8d)')
+    ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--workload', default='aio', choices=['aio', 'single'])
-    ap.add_argument('--batch-gpu', type=int, default=None)
+    ap.add_argument('--batch-gpu', type=int, default=None, help='per-GPU batch (default 32: weak scaling)')
+    ap.add_argument('--global-batch', type=int, default=None,
+                    help='total batch over all ranks, split evenly (strong scaling): --gpus 8 --global-batch 32 is BASELINE configs[4]')
     ap.add_argument('--layers', type=int, default=8)
     ap.add_argument('--res', type=int, default=256)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
@@ -160,9 +191,12 @@ def main():
                          '(~14 min on a fresh box; writes the user db to --miopen-db-out)')
     ap.add_argument('--miopen-find', action='store_true', help='same as --miopen find')
     ap.add_argument('--miopen-db-out', default=None, help='with --miopen find: directory for MIOpen\'s user find-db / perf-db')
-    ap.add_argument('--graphs', default='on', choices=['on', 'off'],
-                    help='record every phase into a HIP graph after 2 eager executions and replay it (phase_engine.PhaseGraphs); '
-                         'implies --ada-margin fixed (a recorded phase cannot read the padding margin back to the host)')
+    ap.add_argument('--graphs', default='auto', choices=['auto', 'on', 'off'],
+                    help='record every phase into a HIP graph after its first eager execution, verify it and replay it '
+                         '(phase_engine.PhaseGraphs); implies --ada-margin fixed (a recorded phase cannot read the padding margin back '
+                         'to the host, and the fixed bound costs ~35 ms of GPU time at batch 32).  auto = on where the step is '
+                         'launch-bound (per-GPU batch <= 16), off where the GPU is the bottleneck anyway')
+    ap.add_argument('--conv-table', default=None, help='write the per-problem convolution table (ms, calls, TFLOP/s) of the profiled steps to this CSV')
     ap.add_argument('--quiet', action='store_true')
     ap.add_argument('--layout', choices=['nhwc', 'nchw'], default='nhwc',
                     help='memory layout of the reduced-precision blocks (the reference\'s fp16_channels_last option): nhwc keeps MIOpen\'s '
@@ -173,8 +207,17 @@ def main():
     ap.add_argument('--host-profile', default=None, help='path prefix: cProfile the host over the timed steps (diagnostic; perturbs the timing)')
     ap.add_argument('--marker-file', default=None, help='write clock readings at the start/end of the timed region (for cutting a rocprofv3 trace)')
     args = ap.parse_args()
+    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    scaling = 'weak'
+    if args.global_batch is not None:
+        assert args.batch_gpu is None, '--global-batch and --batch-gpu are exclusive'
+        assert args.global_batch % world_env == 0, f'--global-batch {args.global_batch} does not divide over {world_env} ranks'
+        args.batch_gpu = args.global_batch // world_env
+        scaling = 'strong'
     if args.batch_gpu is None:
         args.batch_gpu = 32
+    if args.graphs == 'auto':
+        args.graphs = 'on' if args.batch_gpu <= 16 else 'off'
     if args.graphs == 'on' and args.ada_margin != 'fixed':
         args.ada_margin = 'fixed'
     if args.miopen_find:
@@ -272,21 +315,31 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel timing of the hand-written kernels (extra steps, outside the timed region)
-    roofline = None
+    # per-kernel timing of the hand-written kernels and of the convolution calls (extra EAGER steps outside the timed
+    # region: a replayed graph bypasses the launch functions that record the HIP events)
+    roofline = roofline_mfma = None
+    prof_counts = None
     if args.prof_steps > 0:
         # every rank runs these steps (they contain the gradient all-reduces); only rank 0 records events
+        CG = mod('torch_utils.ops.conv2d_gradfix')
+        saved_graphs, trainer.graphs = trainer.graphs, None
+        c0 = native.launch_counts()
         if rank == 0:
             native.prof_reset()
             native.prof_enable(True)
+            CG.prof = []
         for _ in range(args.prof_steps):
             trainer.run_iteration()
         torch.cuda.synchronize(device)
-        rec = None
+        trainer.graphs = saved_graphs
+        c1 = native.launch_counts()
+        prof_counts = {k: round((c1[k] - c0[k]) / args.prof_steps, 1) for k in c1 if c1[k] - c0[k]}
+        rec = conv_rec = None
         if rank == 0:
             rec = native.prof_collect()
             native.prof_enable(False)
             native.prof_reset()
+            conv_rec, CG.prof = CG.prof, None
         if rec:
             total_ms = sum(v['ms'] for v in rec.values())
             name, top = max(rec.items(), key=lambda kv: kv[1]['ms'])
@@ -294,28 +347,64 @@ def main():
             # HBM traffic: PMC counters cannot be read from inside this process; profiles/r01_pmc_traffic.json holds the
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement (separate passes, calibrated) of this kernel on its
             # dominant shape as a ratio to the algorithmic bytes; applied here to this run's bytes per launch.
-            traffic = None
-            try:
-                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels'].get(name)
-                if pmc:
-                    traffic = round(pmc['traffic_over_algorithmic'] * top['bytes'] / top['launches'])
-            except Exception:
-                pass
+            traffic = traffic_source = None
+            for src in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, 'profiles', src)))['kernels'].get(name)
+                    if pmc:
+                        traffic = round(pmc['traffic_over_algorithmic'] * top['bytes'] / top['launches'])
+                        traffic_source = f'profiles/{src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE ratio to algorithmic bytes on the dominant shape, applied to this run\'s bytes per launch'
+                        break
+                except Exception:
+                    pass
             roofline = dict(bound='hbm', kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
-                            frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
+                            frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_source,
                             launches_per_step=round(top['launches'] / args.prof_steps, 1),
                             avg_launch_us=round(top['ms'] * 1e3 / top['launches'], 2),
                             algorithmic_bytes_per_launch=round(top['bytes'] / top['launches']),
                             all_kernels={k: dict(ms_per_step=round(v['ms'] / args.prof_steps, 3), launches_per_step=round(v['launches'] / args.prof_steps, 1),
                                                  GBps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1)) for k, v in rec.items()},
                             native_ms_per_step=round(total_ms / args.prof_steps, 3))
+        if conv_rec:
+            # the MFMA half: every convolution call of the step (forward, data gradient, weight gradient through
+            # torch_utils.ops.conv2d_gradfix; MIOpen / CK kernels plus their helper kernels inside the timed interval)
+            peaks = {torch.bfloat16: ('bf16', MFMA_PEAK_TFLOPS_16), torch.float16: ('fp16', MFMA_PEAK_TFLOPS_16), torch.float32: ('fp32', MFMA_PEAK_TFLOPS_F32)}
+            by = {}
+            shapes = {}
+            for flops, dt, ev_a, ev_b, tag in conv_rec:
+                nm, pk = peaks.get(dt, (str(dt), MFMA_PEAK_TFLOPS_F32))
+                ms = ev_a.elapsed_time(ev_b)
+                e = by.setdefault(nm, dict(flops=0.0, ms=0.0, calls=0, peak=pk))
+                e['flops'] += flops; e['ms'] += ms; e['calls'] += 1
+                sh = shapes.setdefault(f'{nm} {tag}', dict(flops=0.0, ms=0.0, calls=0))
+                sh['flops'] += flops; sh['ms'] += ms; sh['calls'] += 1
+            if args.conv_table:
+                rows = sorted(shapes.items(), key=lambda kv: -kv[1]['ms'])
+                with open(args.conv_table, 'w') as fh:
+                    fh.write('# convolution calls of the step by problem (HIP events around each aten call, eager steps; helper kernels included)\n')
+                    fh.write('ms_per_step,calls_per_step,avg_us,TFLOPps,problem\n')
+                    for k, v in rows:
+                        fh.write(f"{v['ms'] / args.prof_steps:.3f},{v['calls'] / args.prof_steps:.1f},{v['ms'] / v['calls'] * 1e3:.1f},{v['flops'] / (v['ms'] * 1e-3) / 1e12:.1f},{k}\n")
+            tot_f, tot_ms = sum(e['flops'] for e in by.values()), sum(e['ms'] for e in by.values())
+            ideal_ms = sum(e['flops'] / (e['peak'] * 1e12) * 1e3 for e in by.values())
+            main_nm = max(by, key=lambda k: by[k]['flops'])
+            m = by[main_nm]
+            roofline_mfma = dict(bound='mfma', ops='all convolution calls of the step (fwd + dgrad + wgrad; HIP events around each aten call, helper kernels included)',
+                                 dtype=main_nm, achieved=round(m['flops'] / (m['ms'] * 1e-3) / 1e12, 1), peak=m['peak'], unit='TFLOP/s',
+                                 frac=round(m['flops'] / (m['ms'] * 1e-3) / 1e12 / m['peak'], 4),
+                                 by_dtype={k: dict(TFLOP_per_step=round(e['flops'] / args.prof_steps / 1e12, 2), ms_per_step=round(e['ms'] / args.prof_steps, 2),
+                                                   calls_per_step=round(e['calls'] / args.prof_steps, 1), TFLOPps=round(e['flops'] / (e['ms'] * 1e-3) / 1e12, 1),
+                                                   peak=e['peak'], frac=round(e['flops'] / (e['ms'] * 1e-3) / 1e12 / e['peak'], 4)) for k, e in by.items()},
+                                 conv_TFLOP_per_step=round(tot_f / args.prof_steps / 1e12, 2), conv_ms_per_step=round(tot_ms / args.prof_steps, 2),
+                                 conv_ms_per_step_at_peak=round(ideal_ms / args.prof_steps, 2),
+                                 whole_step_TFLOPps=round(tot_f / args.prof_steps / (elapsed / args.steps) / 1e12, 1))
 
     if rank == 0:
         imgs = args.batch_gpu * world * args.steps
         out = {
             'metric': 'img/sec (full G+D step), 8-layer 256^2 RGBA' if args.workload == 'aio' else 'img/sec (full G+D step), single StyleGAN2 256^2 RGBA',
             'value': round(imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'host_enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'host_enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': workload + (' [TINY channel counts: smoke only]' if args.tiny else ''), 'global_batch': args.batch_gpu * world,
                        'batch_per_gpu': args.batch_gpu, 'layers': args.layers if args.workload == 'aio' else 1, 'resolution': args.res,
@@ -323,8 +412,13 @@ def main():
                        'conv_solver_selection': {'tuned': 'MIOpen immediate mode over the find-db shipped in tuning/miopen', 'immediate': 'MIOpen immediate-mode heuristics',
                                                  'find': 'MIOpen exhaustive find in this run'}[args.miopen],
                        'parallelism': f'dp{world} (one flat-buffer RCCL all-reduce per phase)',
-                       'native_launches_per_step': {k: round((counts1[k] - counts0[k]) / args.steps, 1) for k in counts1 if counts1[k] - counts0[k]}},
+                       'phase_graphs': (dict(recorded_and_verified=trainer.graphs.captured, replays=trainer.graphs.replays,
+                                            left_eager={str(k): v[:160] for k, v in trainer.graphs.rejected.items()}) if trainer.graphs is not None else 'off'),
+                       'hbm_allocated_GB': round(torch.cuda.max_memory_allocated(device) / 1e9, 1),
+                       'ada_margin': args.ada_margin if not args.no_ada else None,
+                       'native_launches_per_step': prof_counts if prof_counts is not None else {k: round((counts1[k] - counts0[k]) / args.steps, 1) for k in counts1 if counts1[k] - counts0[k]}},
             'roofline': roofline,
+            'roofline_mfma': roofline_mfma,
             'cpu_baseline': None,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -176,6 +176,216 @@ void launch_mix(const void* x, const float* A, const float* t, void* y, int n, i
     else      hipLaunchKernelGGL((channel_mix_kernel<T, C, 1>), dim3(blocks), dim3(256), 0, s, (const T*)x, A, t, (T*)y, hwv, total);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// ADA transform parameters: the per-sample 3x3 geometric matrix (inverse, accumulated right to left), the reflect-padding
+// margin it needs, the sampling matrix theta and the 4x4 colour matrix, from two tables of pre-drawn random numbers.
+// One lane per sample; ~200 aten launches of 3-4 us per AugmentPipe call upstream (training/augment.py:236-330,380-420 build
+// every factor with stack / matmul on [N,3,3] tensors) become one.
+struct AdaCfg {
+    float xflip, rotate90, xint, xint_max, scale, scale_std, rotate, rotate_max, aniso, aniso_std, xfrac, xfrac_std;
+    float brightness, brightness_std, contrast, contrast_std, lumaflip, hue, hue_max, saturation, saturation_std;
+    float width, height, hz_pad;
+    int channels, has_lr;
+    float left[9], right[9];
+};
+
+struct M3 { float m[3][3]; };
+struct M4 { float m[4][4]; };
+
+__device__ __forceinline__ M3 mul3(const M3& a, const M3& b)
+{
+    M3 r;
+    #pragma unroll
+    for (int i = 0; i < 3; i++)
+        #pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float v = 0.f;
+            #pragma unroll
+            for (int k = 0; k < 3; k++) v += a.m[i][k] * b.m[k][j];       // the summation order of a plain matmul
+            r.m[i][j] = v;
+        }
+    return r;
+}
+__device__ __forceinline__ M4 mul4(const M4& a, const M4& b)
+{
+    M4 r;
+    #pragma unroll
+    for (int i = 0; i < 4; i++)
+        #pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float v = 0.f;
+            #pragma unroll
+            for (int k = 0; k < 4; k++) v += a.m[i][k] * b.m[k][j];
+            r.m[i][j] = v;
+        }
+    return r;
+}
+__device__ __forceinline__ M3 scale3(float sx, float sy) { M3 r = {{{sx, 0, 0}, {0, sy, 0}, {0, 0, 1}}}; return r; }
+__device__ __forceinline__ M3 trans3(float tx, float ty) { M3 r = {{{1, 0, tx}, {0, 1, ty}, {0, 0, 1}}}; return r; }
+__device__ __forceinline__ M3 rot3(float th) { M3 r = {{{cosf(th), sinf(-th), 0}, {sinf(th), cosf(th), 0}, {0, 0, 1}}}; return r; }
+
+__global__ void __launch_bounds__(256) ada_params_kernel(const float* __restrict__ U, const float* __restrict__ Z, const float* __restrict__ p_ptr,
+                                                         int n, int nu, int nz, AdaCfg cfg, float* __restrict__ Ginv, float* __restrict__ margin,
+                                                         float* __restrict__ theta, float* __restrict__ Cmat, float* __restrict__ A4, float* __restrict__ t4)
+{
+    __shared__ float red[4][4];
+    const float p = p_ptr[0];
+    const float PI = 3.14159265358979323846f;
+    float mx[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float* u = U + (size_t)i * nu;
+        const float* z = Z + (size_t)i * nz;
+        int iu = 0, iz = 0;
+        M3 G = scale3(1.f, 1.f);
+        if (cfg.xflip > 0) {
+            float v = floorf(u[iu++] * 2.f);
+            v = (u[iu++] < cfg.xflip * p) ? v : 0.f;
+            G = mul3(G, scale3(1.f / (1.f - 2.f * v), 1.f));
+        }
+        if (cfg.rotate90 > 0) {
+            float v = floorf(u[iu++] * 4.f);
+            v = (u[iu++] < cfg.rotate90 * p) ? v : 0.f;
+            G = mul3(G, rot3(-(-(PI / 2.f) * v)));
+        }
+        if (cfg.xint > 0) {
+            float t0 = (u[iu] * 2.f - 1.f) * cfg.xint_max, t1 = (u[iu + 1] * 2.f - 1.f) * cfg.xint_max;
+            iu += 2;
+            const bool on = u[iu++] < cfg.xint * p;
+            t0 = on ? t0 : 0.f; t1 = on ? t1 : 0.f;
+            G = mul3(G, trans3(-rintf(t0 * cfg.width), -rintf(t1 * cfg.height)));
+        }
+        if (cfg.scale > 0) {
+            float sc = exp2f(z[iz++] * cfg.scale_std);
+            sc = (u[iu++] < cfg.scale * p) ? sc : 1.f;
+            G = mul3(G, scale3(1.f / sc, 1.f / sc));
+        }
+        const float p_rot = 1.f - sqrtf(fminf(fmaxf(1.f - cfg.rotate * p, 0.f), 1.f));
+        if (cfg.rotate > 0) {
+            float th = (u[iu++] * 2.f - 1.f) * PI * cfg.rotate_max;
+            th = (u[iu++] < p_rot) ? th : 0.f;
+            G = mul3(G, rot3(-(-th)));
+        }
+        if (cfg.aniso > 0) {
+            float sc = exp2f(z[iz++] * cfg.aniso_std);
+            sc = (u[iu++] < cfg.aniso * p) ? sc : 1.f;
+            G = mul3(G, scale3(1.f / sc, 1.f / (1.f / sc)));
+        }
+        if (cfg.rotate > 0) {
+            float th = (u[iu++] * 2.f - 1.f) * PI * cfg.rotate_max;
+            th = (u[iu++] < p_rot) ? th : 0.f;
+            G = mul3(G, rot3(-(-th)));
+        }
+        if (cfg.xfrac > 0) {
+            float t0 = z[iz] * cfg.xfrac_std, t1 = z[iz + 1] * cfg.xfrac_std;
+            iz += 2;
+            const bool on = u[iu++] < cfg.xfrac * p;
+            t0 = on ? t0 : 0.f; t1 = on ? t1 : 0.f;
+            G = mul3(G, trans3(-(t0 * cfg.width), -(t1 * cfg.height)));
+        }
+        if (Ginv) {
+            #pragma unroll
+            for (int a = 0; a < 3; a++)
+                #pragma unroll
+                for (int b = 0; b < 3; b++) Ginv[(size_t)i * 9 + a * 3 + b] = G.m[a][b];
+            // transformed image corners -> how far the reflect padding must reach (per axis and side)
+            const float cx = (cfg.width - 1.f) / 2.f, cy = (cfg.height - 1.f) / 2.f;
+            const float xs[4] = {-cx, cx, cx, -cx}, ys[4] = {-cy, -cy, cy, cy};
+            #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float X = G.m[0][0] * xs[k] + G.m[0][1] * ys[k] + G.m[0][2];
+                float Y = G.m[1][0] * xs[k] + G.m[1][1] * ys[k] + G.m[1][2];
+                mx[0] = fmaxf(mx[0], -X); mx[1] = fmaxf(mx[1], -Y); mx[2] = fmaxf(mx[2], X); mx[3] = fmaxf(mx[3], Y);
+            }
+            if (theta && cfg.has_lr) {
+                M3 L, R;
+                #pragma unroll
+                for (int a = 0; a < 9; a++) { L.m[a / 3][a % 3] = cfg.left[a]; R.m[a / 3][a % 3] = cfg.right[a]; }
+                M3 T = mul3(mul3(L, G), R);
+                #pragma unroll
+                for (int a = 0; a < 2; a++)
+                    #pragma unroll
+                    for (int b = 0; b < 3; b++) theta[(size_t)i * 6 + a * 3 + b] = T.m[a][b];
+            }
+        }
+        if (Cmat) {
+            M4 C = {{{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}}};
+            const float vv_ = 0.57735026918962576451f;      // 1 / sqrt(3): the luma axis (1,1,1,0)/sqrt(3)
+            const float v[4] = {vv_, vv_, vv_, 0.f};
+            if (cfg.brightness > 0) {
+                float b = z[iz++] * cfg.brightness_std;
+                b = (u[iu++] < cfg.brightness * p) ? b : 0.f;
+                M4 T = {{{1, 0, 0, b}, {0, 1, 0, b}, {0, 0, 1, b}, {0, 0, 0, 1}}};
+                C = mul4(T, C);
+            }
+            if (cfg.contrast > 0) {
+                float c = exp2f(z[iz++] * cfg.contrast_std);
+                c = (u[iu++] < cfg.contrast * p) ? c : 1.f;
+                M4 S = {{{c, 0, 0, 0}, {0, c, 0, 0}, {0, 0, c, 0}, {0, 0, 0, 1}}};
+                C = mul4(S, C);
+            }
+            if (cfg.lumaflip > 0) {
+                float f = floorf(u[iu++] * 2.f);
+                f = (u[iu++] < cfg.lumaflip * p) ? f : 0.f;
+                M4 H;
+                #pragma unroll
+                for (int a = 0; a < 4; a++)
+                    #pragma unroll
+                    for (int b = 0; b < 4; b++) H.m[a][b] = (a == b ? 1.f : 0.f) - 2.f * (v[a] * v[b]) * f;       // Householder reflection
+                C = mul4(H, C);
+            }
+            if (cfg.hue > 0 && cfg.channels > 1) {
+                float th = (u[iu++] * 2.f - 1.f) * PI * cfg.hue_max;
+                th = (u[iu++] < cfg.hue * p) ? th : 0.f;
+                const float s = sinf(th), c = cosf(th), cc = 1.f - c;
+                const float vx = v[0], vy = v[1], vz = v[2];
+                M4 R = {{{vx * vx * cc + c, vx * vy * cc - vz * s, vx * vz * cc + vy * s, 0},
+                         {vy * vx * cc + vz * s, vy * vy * cc + c, vy * vz * cc - vx * s, 0},
+                         {vz * vx * cc - vy * s, vz * vy * cc + vx * s, vz * vz * cc + c, 0},
+                         {0, 0, 0, 1}}};
+                C = mul4(R, C);
+            }
+            if (cfg.saturation > 0 && cfg.channels > 1) {
+                float sa = exp2f(z[iz++] * cfg.saturation_std);
+                sa = (u[iu++] < cfg.saturation * p) ? sa : 1.f;
+                M4 S;
+                #pragma unroll
+                for (int a = 0; a < 4; a++)
+                    #pragma unroll
+                    for (int b = 0; b < 4; b++) { float vvab = v[a] * v[b]; S.m[a][b] = vvab + ((a == b ? 1.f : 0.f) - vvab) * sa; }
+                C = mul4(S, C);
+            }
+            #pragma unroll
+            for (int a = 0; a < 4; a++)
+                #pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    Cmat[(size_t)i * 16 + a * 4 + b] = C.m[a][b];
+                    if (A4) A4[(size_t)i * 16 + a * 4 + b] = (a < 3 && b < 3) ? C.m[a][b] : (a == b ? 1.f : 0.f);     // RGBA: colour block only
+                }
+            if (t4) {
+                #pragma unroll
+                for (int a = 0; a < 4; a++) t4[(size_t)i * 4 + a] = a < 3 ? C.m[a][3] : 0.f;
+            }
+        }
+    }
+    if (margin) {
+        #pragma unroll
+        for (int k = 0; k < 4; k++)
+            for (int off = 32; off > 0; off >>= 1) mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off, 64));
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) { for (int k = 0; k < 4; k++) red[wave][k] = mx[k]; }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const int k = threadIdx.x;
+            float m = fmaxf(fmaxf(red[0][k], red[1][k]), fmaxf(red[2][k], red[3][k]));
+            const float cx = (cfg.width - 1.f) / 2.f, cy = (cfg.height - 1.f) / 2.f;
+            m += (k & 1) ? (cfg.hz_pad * 2.f - cy) : (cfg.hz_pad * 2.f - cx);
+            m = fminf(fmaxf(m, 0.f), (k & 1) ? cfg.height - 1.f : cfg.width - 1.f);
+            margin[k] = m;
+        }
+    }
+}
+
 } // namespace
 
 extern "C" int mg_affine_warp_fwd(const void* x, const float* theta, void* y, int dtype, int32_t n, int32_t c,
@@ -242,4 +452,44 @@ extern "C" int mg_channel_mix(const void* x, const float* A, const float* t, voi
         }
     });
     return mg_check_launch(MG_K_CHANNEL_MIX, "channel_mix");
+}
+
+extern "C" int mg_ada_params(const float* U, const float* Z, const float* p, int32_t n, int32_t nu, int32_t nz, const float* cfg, int32_t ncfg,
+                             float* Ginv, float* margin, float* theta, float* Cmat, float* A4, float* t4, void* stream)
+{
+    MG_REQUIRE(U && Z && p && cfg, "ada_params: null pointer");
+    MG_REQUIRE(ncfg == 26 + 18, "ada_params: the configuration vector has %d entries, expected 44", (int)ncfg);
+    MG_REQUIRE(n >= 0 && nu >= 0 && nz >= 0, "ada_params: bad shape");
+    if (n == 0) return MG_OK;
+    AdaCfg c;
+    const float* f = cfg;
+    c.xflip = f[0]; c.rotate90 = f[1]; c.xint = f[2]; c.xint_max = f[3]; c.scale = f[4]; c.scale_std = f[5]; c.rotate = f[6]; c.rotate_max = f[7];
+    c.aniso = f[8]; c.aniso_std = f[9]; c.xfrac = f[10]; c.xfrac_std = f[11]; c.brightness = f[12]; c.brightness_std = f[13]; c.contrast = f[14];
+    c.contrast_std = f[15]; c.lumaflip = f[16]; c.hue = f[17]; c.hue_max = f[18]; c.saturation = f[19]; c.saturation_std = f[20];
+    c.width = f[21]; c.height = f[22]; c.hz_pad = f[23]; c.channels = (int)f[24]; c.has_lr = (int)f[25];
+    for (int i = 0; i < 9; i++) { c.left[i] = f[26 + i]; c.right[i] = f[35 + i]; }
+    // the columns the enabled transforms consume, in the order the kernel walks them
+    int need_u = 0, need_z = 0;
+    if (Ginv) {
+        if (c.xflip > 0) need_u += 2;
+        if (c.rotate90 > 0) need_u += 2;
+        if (c.xint > 0) need_u += 3;
+        if (c.scale > 0) { need_u += 1; need_z += 1; }
+        if (c.rotate > 0) need_u += 4;
+        if (c.aniso > 0) { need_u += 1; need_z += 1; }
+        if (c.xfrac > 0) { need_u += 1; need_z += 2; }
+    }
+    if (Cmat) {
+        if (c.brightness > 0) { need_u += 1; need_z += 1; }
+        if (c.contrast > 0) { need_u += 1; need_z += 1; }
+        if (c.lumaflip > 0) need_u += 2;
+        if (c.hue > 0 && c.channels > 1) need_u += 2;
+        if (c.saturation > 0 && c.channels > 1) { need_u += 1; need_z += 1; }
+    }
+    MG_REQUIRE(nu >= need_u && nz >= need_z, "ada_params: random tables have %d / %d columns, the enabled transforms need %d / %d", (int)nu, (int)nz, need_u, need_z);
+    MG_REQUIRE(!theta || (Ginv && c.has_lr), "ada_params: theta needs the geometric stage and the left / right factors");
+    hipStream_t s = (hipStream_t)stream;
+    MgLaunchScope scope(MG_K_ADA_PARAMS, s, (double)n * (nu + nz + 9 + 6 + 16 + 16 + 4) * 4);
+    hipLaunchKernelGGL(ada_params_kernel, dim3(1), dim3(256), 0, s, U, Z, p, n, nu, nz, c, Ginv, margin, theta, Cmat, A4, t4);
+    return mg_check_launch(MG_K_ADA_PARAMS, "ada_params");
 }

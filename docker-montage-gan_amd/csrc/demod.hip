@@ -13,18 +13,54 @@ namespace {
 
 constexpr int DM_MAXN = 256;        // samples per launch (one value per lane slice in LDS)
 
-// block = one output channel o; 256 lanes = 8 slices of the input channels x up to 32 samples per pass
+constexpr int DM_MAXKK = 9;         // taps per (o, i) pair the coalesced paths stage (1x1 and 3x3 kernels); larger kernels read strided
+
+// Weight layouts: CL = 0: [O][I][kk] (contiguous), CL = 1: [O][kk][I] (torch.channels_last of [O,I,kh,kw]).  Either way one
+// output channel's weights are ONE contiguous run of I*kk floats, which the kernels below read / write with consecutive
+// lanes on consecutive addresses.
+
+// block = one output channel o.  Phase 1: wsq[o,i] = sum_k w^2 (coalesced), phase 2: 8 lanes per sample over the input channels.
+template <int CL>
 __global__ void __launch_bounds__(256) demod_fwd_kernel(const float* __restrict__ w, const float* __restrict__ s, float* __restrict__ d,
                                                        float* __restrict__ wsq, int n, int o_total, int ic, int kk)
 {
-    extern __shared__ float s_wsq[];                // [ic]
+    extern __shared__ float sm[];                   // [ic] squared sums, then (CL = 0) a staging tile of 256 * kk floats
+    float* s_wsq = sm;
     const int o = blockIdx.x;
     const float* wp = w + (size_t)o * ic * kk;
-    for (int i = threadIdx.x; i < ic; i += 256) {
-        float a = 0.f;
-        for (int k = 0; k < kk; k++) { const float v = wp[(size_t)i * kk + k]; a = __builtin_fmaf(v, v, a); }
-        s_wsq[i] = a;
-        wsq[(size_t)o * ic + i] = a;
+    if (CL == 1) {
+        // [kk][I]: lane t owns channels t, t+256, ...; for a fixed tap consecutive lanes read consecutive floats
+        for (int i = threadIdx.x; i < ic; i += 256) {
+            float a = 0.f;
+            for (int k = 0; k < kk; k++) { const float v = wp[(size_t)k * ic + i]; a = __builtin_fmaf(v, v, a); }
+            s_wsq[i] = a;
+            wsq[(size_t)o * ic + i] = a;
+        }
+    } else if (kk <= DM_MAXKK) {
+        // [I][kk]: stage 256 channels x kk taps (one contiguous run) into LDS with coalesced loads, then lane t sums its kk
+        // neighbours (stride kk = 1 or 9 words: conflict-free)
+        float* tile = sm + ic;
+        for (int i0 = 0; i0 < ic; i0 += 256) {
+            const int cnt = min(256, ic - i0) * kk;
+            const float* src = wp + (size_t)i0 * kk;
+            for (int e = threadIdx.x; e < cnt; e += 256) tile[e] = src[e];
+            __syncthreads();
+            const int i = i0 + threadIdx.x;
+            if (i < ic) {
+                float a = 0.f;
+                for (int k = 0; k < kk; k++) { const float v = tile[threadIdx.x * kk + k]; a = __builtin_fmaf(v, v, a); }
+                s_wsq[i] = a;
+                wsq[(size_t)o * ic + i] = a;
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int i = threadIdx.x; i < ic; i += 256) {
+            float a = 0.f;
+            for (int k = 0; k < kk; k++) { const float v = wp[(size_t)i * kk + k]; a = __builtin_fmaf(v, v, a); }
+            s_wsq[i] = a;
+            wsq[(size_t)o * ic + i] = a;
+        }
     }
     __syncthreads();
     // each group of 8 lanes handles one sample: lane q of the group sums i = q, q+8, ...
@@ -38,11 +74,14 @@ __global__ void __launch_bounds__(256) demod_fwd_kernel(const float* __restrict_
     }
 }
 
-// dw[o,i,k] = 2 w[o,i,k] * sum_n t[n,o] s[n,i]^2,  t = -0.5 g d^3.   block = one output channel
+// dw[o,i,k] = 2 w[o,i,k] * sum_n t[n,o] s[n,i]^2,  t = -0.5 g d^3.   block = one output channel; dw has w's layout
+template <int CL>
 __global__ void __launch_bounds__(256) demod_bwd_w_kernel(const float* __restrict__ w, const float* __restrict__ s, const float* __restrict__ d,
                                                          const float* __restrict__ g, float* __restrict__ dw, int n, int o_total, int ic, int kk)
 {
-    __shared__ float s_t[DM_MAXN];
+    extern __shared__ float sm[];                   // [DM_MAXN] t, then [ic] per-channel factors
+    float* s_t = sm;
+    float* s_a = sm + DM_MAXN;
     const int o = blockIdx.x;
     for (int nn = threadIdx.x; nn < n; nn += 256) {
         const float dv = d[(size_t)nn * o_total + o];
@@ -52,9 +91,16 @@ __global__ void __launch_bounds__(256) demod_bwd_w_kernel(const float* __restric
     for (int i = threadIdx.x; i < ic; i += 256) {
         float a = 0.f;
         for (int nn = 0; nn < n; nn++) { const float v = s[(size_t)nn * ic + i]; a = __builtin_fmaf(s_t[nn], v * v, a); }
-        a *= 2.f;
-        const size_t base = ((size_t)o * ic + i) * kk;
-        for (int k = 0; k < kk; k++) dw[base + k] = w[base + k] * a;
+        s_a[i] = a * 2.f;
+    }
+    __syncthreads();
+    // one contiguous run of ic * kk floats, consecutive lanes on consecutive addresses; the channel of flat element e is
+    // e / kk ([I][kk]) or e % ic ([kk][I])
+    const size_t base = (size_t)o * ic * kk;
+    const int total = ic * kk;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int i = CL ? (e % ic) : (e / kk);
+        dw[base + e] = w[base + e] * s_a[i];
     }
 }
 
@@ -85,26 +131,32 @@ __global__ void __launch_bounds__(256) demod_bwd_s_kernel(const float* __restric
 } // namespace
 
 extern "C" int mg_demod_fwd(const float* w, const float* s, float* d, float* wsq, int32_t n, int32_t oc, int32_t ic, int32_t kk,
-                            void* stream)
+                            int32_t channels_last, void* stream)
 {
     MG_REQUIRE(w && s && d && wsq, "w must reside on the device");
-    MG_REQUIRE(n >= 0 && oc >= 1 && ic >= 1 && kk >= 1 && ic <= 16384, "demod: bad shape");
+    MG_REQUIRE(n >= 0 && oc >= 1 && ic >= 1 && kk >= 1 && ic <= 8192, "demod: bad shape");
     if (n == 0) return MG_OK;
     hipStream_t st = (hipStream_t)stream;
     MgLaunchScope scope(MG_K_DEMOD, st, 4.0 * ((double)oc * ic * kk + (double)n * ic + (double)n * oc));
-    hipLaunchKernelGGL(demod_fwd_kernel, dim3((uint32_t)oc), dim3(256), sizeof(float) * (size_t)ic, st, w, s, d, wsq, n, oc, ic, kk);
+    const size_t lds = sizeof(float) * ((size_t)ic + (channels_last ? 0 : 256 * DM_MAXKK));
+    if (channels_last) hipLaunchKernelGGL(demod_fwd_kernel<1>, dim3((uint32_t)oc), dim3(256), lds, st, w, s, d, wsq, n, oc, ic, kk);
+    else               hipLaunchKernelGGL(demod_fwd_kernel<0>, dim3((uint32_t)oc), dim3(256), lds, st, w, s, d, wsq, n, oc, ic, kk);
     return mg_check_launch(MG_K_DEMOD, "demod_fwd");
 }
 
 extern "C" int mg_demod_bwd(const float* w, const float* s, const float* d, const float* wsq, const float* g, float* ds, float* dw,
-                            int32_t n, int32_t oc, int32_t ic, int32_t kk, void* stream)
+                            int32_t n, int32_t oc, int32_t ic, int32_t kk, int32_t channels_last, void* stream)
 {
     MG_REQUIRE(w && s && d && wsq && g, "w must reside on the device");
-    MG_REQUIRE(n >= 0 && n <= DM_MAXN && oc >= 1 && oc <= 16384 && ic >= 1 && kk >= 1, "demod: bad shape (at most %d samples)", DM_MAXN);
+    MG_REQUIRE(n >= 0 && n <= DM_MAXN && oc >= 1 && oc <= 16384 && ic >= 1 && ic <= 8192 && kk >= 1, "demod: bad shape (at most %d samples)", DM_MAXN);
     if (n == 0) return MG_OK;
     hipStream_t st = (hipStream_t)stream;
     MgLaunchScope scope(MG_K_DEMOD, st, 4.0 * (2.0 * oc * ic * kk + 2.0 * n * ic + 2.0 * n * oc + (double)oc * ic));
-    if (dw) hipLaunchKernelGGL(demod_bwd_w_kernel, dim3((uint32_t)oc), dim3(256), 0, st, w, s, d, g, dw, n, oc, ic, kk);
+    if (dw) {
+        const size_t lds = sizeof(float) * ((size_t)DM_MAXN + ic);
+        if (channels_last) hipLaunchKernelGGL(demod_bwd_w_kernel<1>, dim3((uint32_t)oc), dim3(256), lds, st, w, s, d, g, dw, n, oc, ic, kk);
+        else               hipLaunchKernelGGL(demod_bwd_w_kernel<0>, dim3((uint32_t)oc), dim3(256), lds, st, w, s, d, g, dw, n, oc, ic, kk);
+    }
     if (ds) {
         const int tiles_i = (ic + 63) / 64;
         hipLaunchKernelGGL(demod_bwd_s_kernel, dim3((uint32_t)(n * tiles_i)), dim3(256), sizeof(float) * ((size_t)oc + 256), st, s, d, g, wsq, ds, oc, ic, tiles_i);

@@ -104,7 +104,7 @@ class AioTrainer:
                  D_reg_interval=16, local_G_opt_kwargs=None, local_D_opt_kwargs=None, global_G_opt_kwargs=None,
                  global_D_opt_kwargs=None, loss_kwargs=None, augment_kwargs=None, augment_p=0, ada_target=None,
                  ada_interval=4, ada_kimg=500, resume_kimg=0.0, cfg=None, rcfg=None, resident_batches=None, graphs=False,
-                 graph_warmup=1, grad_wire_dtype=None, **_unused):
+                 graph_warmup=1, graph_verify=True, grad_wire_dtype=None, **_unused):
         cfg = dict(config if cfg is None else cfg)
         rcfg = dict(renderer_config if rcfg is None else rcfg)
         if not cfg['train_global']:
@@ -131,7 +131,7 @@ class AioTrainer:
         # from then on (phase_engine.PhaseGraphs); needs optimizers whose step counter lives on the device.
         self.graphs = None
         if graphs and device.type == 'cuda':
-            self.graphs = phase_engine.PhaseGraphs(device, warmup=graph_warmup)
+            self.graphs = phase_engine.PhaseGraphs(device, warmup=graph_warmup, verify=graph_verify)
         self._static = None         # persistent input tensors of the phases (refreshed in place every iteration)
 
         cci = cfg['conv_config_index']
@@ -286,9 +286,24 @@ class AioTrainer:
             for round_idx, (real_layer, gen_z, real_list) in enumerate(zip(st.blchw, gen_z_rounds, st.lists)):
                 self.loss.accumulate_gradients(phase=phase.name, real_blchw=real_layer, real_list_of_bchw=real_list, gen_z=gen_z,
                                                sync=(round_idx == rounds - 1), gain=phase.interval)
-        phase_engine.run_phase(phase, accumulate, self.grad_sync, self.graphs, self.num_gpus)
+        phase_engine.run_phase(phase, accumulate, self.grad_sync, self.graphs, self.num_gpus, state_fn=lambda: self._phase_state(phase))
+
+    def _phase_state(self, phase):
+        mods = [self.mapping_network, *self.local_G_list, *self.local_D_list, self.pos_estimator, self.global_D, self.renderer]
+        extra = [l.pl_mean for l in self.loss.local_GAN_loss_list]
+        extra += [t for per_dev in training_stats._counters.values() for t in per_dev.values()]
+        if not hasattr(self, '_param_names'):
+            self._param_names = {id(p): f'{type(m).__name__}{i}.{n}' for i, m in enumerate(mods) if m is not None for n, p in m.named_parameters()}
+        return phase_engine.phase_state(phase, mods, extra, flat=self.grad_sync._flat.get(id(phase.opt)), names=self._param_names)
 
     def run_iteration(self):
+        """One loop iteration; with phase graphs everything runs on the recording stream (PhaseGraphs.stream_scope)."""
+        if self.graphs is None:
+            return self._run_iteration()
+        with self.graphs.stream_scope():
+            return self._run_iteration()
+
+    def _run_iteration(self):
         """One loop iteration (reference :597-688): data, every phase whose interval divides batch_idx,
         EMA, ADA.  Returns the number of phases executed."""
         device = self.device

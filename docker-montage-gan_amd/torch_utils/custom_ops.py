@@ -6,11 +6,17 @@ functions as the reference's pybind modules:
     upfirdn2d_plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
     bias_act_plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)
 
-Behind them is libmontage_hip.so (C ABI in include/montage_hip.h), compiled ahead of time
-for gfx950 instead of JIT-built per process, so there is no FileBaton / md5 build cache to
-keep.  ``sources`` and ``build_kwargs`` are accepted for call compatibility and ignored.
+They are the functions of a ``torch.utils.cpp_extension`` pybind module (csrc/torch_plugin.cpp: at::Tensor arguments,
+TORCH_CHECK validation, output allocation with ``suggest_memory_format``, PyTorch's current HIP stream) over the C ABI of
+libmontage_hip.so (include/montage_hip.h) -- the "C-ABI shim" of the reference's loader (custom_ops.py:49-129).  Both
+are compiled ahead of time and in-tree (``native.build()``) instead of JIT-built per process, so there is no FileBaton / md5
+build cache to keep; if the shim is missing, ``get_plugin`` builds it on the spot from ``sources`` (``.cpp`` files; default
+csrc/torch_plugin.cpp) with ``build_kwargs`` (extra_cflags / extra_ldflags / extra_include_paths).  ``MONTAGE_PLUGIN=ctypes``
+selects the pure-ctypes binding of the same C ABI instead (what tests/test_abi_cpu.py exercises without a GPU).
 A load failure RAISES; callers never get a silent slow path.
 """
+import os
+
 import torch
 
 from . import native
@@ -161,6 +167,17 @@ class _BiasActPlugin:
 _PLUGINS = {'upfirdn2d_plugin': _Upfirdn2dPlugin, 'bias_act_plugin': _BiasActPlugin}
 
 
+class _TorchPlugin:
+    """One reference plugin name -> the functions of the shared pybind module."""
+
+    def __init__(self, mod, names):
+        for n in names:
+            setattr(self, n, getattr(mod, n))
+
+
+_EXPORTS = {'upfirdn2d_plugin': ('upfirdn2d',), 'bias_act_plugin': ('bias_act',)}
+
+
 def get_plugin(module_name, sources=None, **build_kwargs):
     assert verbosity in ['none', 'brief', 'full']
     if module_name in _cached_plugins:
@@ -171,12 +188,19 @@ def get_plugin(module_name, sources=None, **build_kwargs):
         print(f'Setting up PyTorch plugin "{module_name}"... ', end='', flush=True)
     try:
         native.lib()          # raises when the shared library is missing
+        if os.environ.get('MONTAGE_PLUGIN', 'torch') == 'ctypes':
+            plugin = _PLUGINS[module_name]
+        else:
+            if not os.path.exists(native.torch_plugin_path()):
+                cpp = [s for s in (sources or []) if str(s).endswith('.cpp') and os.path.exists(s)]
+                native.build_torch_plugin(sources=cpp or None, verbose=(verbosity == 'full'),
+                                          **{k: v for k, v in build_kwargs.items() if k in ('extra_cflags', 'extra_ldflags', 'extra_include_paths')})
+            plugin = _TorchPlugin(native.torch_plugin(), _EXPORTS[module_name])
     except Exception:
         if verbosity != 'none':
             print('Failed!')
         raise
     if verbosity != 'none':
         print('Done.')
-    plugin = _PLUGINS[module_name]
     _cached_plugins[module_name] = plugin
     return plugin

@@ -22,24 +22,86 @@ K_UPFIRDN2D_NHWC = 12
 K_AFFINE_WARP_FWD, K_AFFINE_WARP_BWD, K_CHANNEL_MIX = 13, 14, 15
 K_DEMOD = 16
 K_LINEAR = 17
+K_STATS = 18
+K_ADA_PARAMS = 19
 GS_SLOTS = 64       # MG_GS_SLOTS
 KERNEL_NAMES = {0: 'upfirdn2d_generic', 1: 'upfirdn2d_tiled', 2: 'bias_act', 3: 'fma_bias_act', 4: 'alpha_composite_fwd',
                 5: 'alpha_composite_bwd', 6: 'translate_fwd', 7: 'translate_bwd_input', 8: 'translate_bwd_shift',
                 9: 'filtered_lrelu', 10: 'bwd_fused', 11: 'upfirdn2d_stream', 12: 'upfirdn2d_nhwc',
-                13: 'affine_warp_fwd', 14: 'affine_warp_bwd', 15: 'channel_mix', 16: 'demod', 17: 'linear'}
+                13: 'affine_warp_fwd', 14: 'affine_warp_bwd', 15: 'channel_mix', 16: 'demod', 17: 'linear', 18: 'stats', 19: 'ada_params'}
 
 _lib = None
-_lock = threading.Lock()
+_lock = threading.RLock()
 
 c_int, c_i32, c_i64, c_float, c_void_p = ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 I32x4, I64x4, I32x2, I64x2 = c_i32 * 4, c_i64 * 4, c_i32 * 2, c_i64 * 2
 
 
 def build(verbose=False):
-    """Compile every HIP source for gfx950 into csrc/libmontage_hip.so (hipcc cross-compiles without a GPU)."""
+    """Compile every HIP source for gfx950 into csrc/libmontage_hip.so (hipcc cross-compiles without a GPU) and the
+    torch.utils.cpp_extension shim on top of it (csrc/torch_plugin.cpp -> csrc/montage_torch_plugin*.so)."""
     out = None if verbose else subprocess.DEVNULL
     subprocess.run(['make', '-C', CSRC, '-j', str(min(8, os.cpu_count() or 1))], check=True, stdout=out)
+    build_torch_plugin(verbose=verbose)
     return LIB_PATH
+
+
+TORCH_PLUGIN_NAME = 'montage_torch_plugin'
+
+
+def torch_plugin_path():
+    import sysconfig
+    return os.path.join(CSRC, TORCH_PLUGIN_NAME + sysconfig.get_config_var('EXT_SUFFIX'))
+
+
+def build_torch_plugin(sources=None, verbose=False, force=False, **build_kwargs):
+    """The pybind11 / ATen shim (host C++ only: tensors in, C ABI out).  Ahead of time and in-tree -- the same compiler
+    invocation ``torch.utils.cpp_extension`` would issue for a ``.cpp``-only extension (its include paths, its ABI and ROCm
+    defines), without the per-process JIT cache, so that the built module travels with the tree.  `sources` defaults to
+    csrc/torch_plugin.cpp; `build_kwargs` understands ``extra_cflags`` / ``extra_ldflags`` / ``extra_include_paths``."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    srcs = [os.path.join(CSRC, 'torch_plugin.cpp')] if not sources else list(sources)
+    out = torch_plugin_path()
+    deps = srcs + [os.path.join(os.path.dirname(os.path.dirname(CSRC)), 'include', 'montage_hip.h'), LIB_PATH]
+    if not force and os.path.exists(out) and all(os.path.exists(d) and os.path.getmtime(d) <= os.path.getmtime(out) for d in deps[:-1]):
+        return out
+    libdir = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    cmd = [os.environ.get('CXX', 'g++'), '-O2', '-fPIC', '-shared', '-std=c++17', '-D__HIP_PLATFORM_AMD__=1', '-DUSE_ROCM=1',
+           f'-DTORCH_EXTENSION_NAME={TORCH_PLUGIN_NAME}', '-DTORCH_API_INCLUDE_EXTENSION_H',
+           f'-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}'] + list(build_kwargs.get('extra_cflags', []))
+    for inc in ce.include_paths() + [os.path.join(ce.ROCM_HOME or '/opt/rocm', 'include'), sysconfig.get_paths()['include']] + \
+            list(build_kwargs.get('extra_include_paths', [])):
+        cmd += ['-isystem', inc]
+    cmd += srcs + ['-o', out, '-L' + libdir, '-lc10', '-lc10_hip', '-ltorch', '-ltorch_cpu', '-ltorch_hip', '-ltorch_python',
+                   '-L' + CSRC, '-lmontage_hip', '-Wl,-rpath,$ORIGIN', '-Wl,-rpath,' + libdir] + list(build_kwargs.get('extra_ldflags', []))
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    return out
+
+
+_torch_plugin = None
+
+
+def torch_plugin():
+    """The loaded pybind module (csrc/montage_torch_plugin*.so).  Raises when it has not been built."""
+    global _torch_plugin
+    if _torch_plugin is None:
+        with _lock:
+            if _torch_plugin is None:
+                import importlib.util
+                import torch  # noqa: F401  (libtorch must be loaded before the extension)
+                path = torch_plugin_path()
+                if not os.path.exists(path):
+                    raise RuntimeError(f'{path} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"`')
+                lib()           # libmontage_hip.so first: same search path for the extension's DT_NEEDED entry
+                spec = importlib.util.spec_from_file_location(TORCH_PLUGIN_NAME, path)
+                m = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(m)
+                _torch_plugin = m
+    return _torch_plugin
 
 
 def _declare(L):
@@ -54,8 +116,10 @@ def _declare(L):
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]
     L.mg_linear_fwd.argtypes = [c_void_p] * 4 + [c_i32] * 3 + [c_void_p]
     L.mg_linear_bwd.argtypes = [c_void_p] * 6 + [c_i32] * 3 + [c_void_p]
-    L.mg_demod_fwd.argtypes = [c_void_p] * 4 + [c_i32] * 4 + [c_void_p]
-    L.mg_demod_bwd.argtypes = [c_void_p] * 7 + [c_i32] * 4 + [c_void_p]
+    L.mg_demod_fwd.argtypes = [c_void_p] * 4 + [c_i32] * 5 + [c_void_p]
+    L.mg_demod_bwd.argtypes = [c_void_p] * 7 + [c_i32] * 5 + [c_void_p]
+    L.mg_ada_params.argtypes = [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, ctypes.POINTER(c_float), c_i32] + [c_void_p] * 7
+    L.mg_stats_accumulate.argtypes = [c_void_p, c_int, c_i64, c_void_p, c_void_p]
     L.mg_upfirdn2d_sep.argtypes = [c_void_p, c_void_p, c_void_p, c_int] + [c_i32] * 7 + [c_int] * 7 + [c_float, c_void_p]
     L.mg_upfirdn2d_index_table.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     L.mg_bias_act.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -79,7 +143,7 @@ def _declare(L):
     for name in ('mg_upfirdn2d', 'mg_upfirdn2d_sep', 'mg_upfirdn2d_index_table', 'mg_bias_act', 'mg_fma_bias_act',
                  'mg_alpha_composite_fwd', 'mg_alpha_composite_bwd', 'mg_translate_sample_fwd',
                  'mg_translate_sample_bwd_input', 'mg_translate_sample_bwd_shift', 'mg_filtered_lrelu', 'mg_bwd_fused',
-                 'mg_fma_bias_act_nhwc', 'mg_bwd_fused_nhwc', 'mg_affine_warp_fwd', 'mg_affine_warp_bwd', 'mg_channel_mix', 'mg_demod_fwd', 'mg_demod_bwd', 'mg_linear_fwd', 'mg_linear_bwd',
+                 'mg_fma_bias_act_nhwc', 'mg_bwd_fused_nhwc', 'mg_affine_warp_fwd', 'mg_affine_warp_bwd', 'mg_channel_mix', 'mg_demod_fwd', 'mg_demod_bwd', 'mg_linear_fwd', 'mg_linear_bwd', 'mg_stats_accumulate', 'mg_ada_params',
                  'mg_prof_enable', 'mg_prof_collect', 'mg_prof_reset'):
         getattr(L, name).restype = c_int
 

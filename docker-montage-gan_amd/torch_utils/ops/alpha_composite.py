@@ -52,6 +52,14 @@ class _AlphaCompositeHip(torch.autograd.Function):
     def backward(ctx, dy):
         x, = ctx.saved_tensors
         b, l, c, h, w = x.shape
+        if torch.is_grad_enabled():
+            # create_graph=True (the R1 penalty of the global discriminator differentiates its input gradient again,
+            # reference custom/loss_aio.py:327-335): the gradient as a differentiable function of (x, dy), from the aten
+            # recurrence.  The native kernel below returns a constant as far as autograd is concerned.
+            with torch.enable_grad():
+                y = _alpha_composite_ref(x)
+                dx, = torch.autograd.grad([y], [x], [dy], create_graph=True)
+            return dx, None
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         with native.guard(x.device):
@@ -67,7 +75,7 @@ def alpha_composite(blchw_lchw, safe_grad=False, impl='cuda'):
     safe_grad=False reproduces the reference's autograd bit for bit in where it yields NaN
     (pixels whose accumulated alpha is exactly 0 give 0/0 in the backward of the division);
     safe_grad=True gives those pixels a zero gradient instead (conscious deviation, opt-in).
-    Only first-order gradients on the native path."""
+    Second-order gradients (create_graph=True) go through the aten recurrence."""
     assert isinstance(blchw_lchw, torch.Tensor) and blchw_lchw.ndim in (4, 5)
     assert impl in ['ref', 'cuda']
     x = blchw_lchw

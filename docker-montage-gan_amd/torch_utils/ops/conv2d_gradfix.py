@@ -57,6 +57,41 @@ def _should_use_custom_op(input):
     return bool(enabled)
 
 
+# Measurement hook (bench.py's MFMA roofline leg): while ``prof`` is a list, every convolution call made through this
+# module appends (flops, dtype, start_event, end_event) -- HIP events on the launch stream around the aten call, so the
+# interval covers the library's helper kernels (layout transposes, split-K zero fills) as well as the MFMA kernel.
+prof = None
+
+
+class _Timed:
+    __slots__ = ('flops', 'dtype', 'a', 'tag')
+
+    def __init__(self, flops, dtype, tag=None):
+        self.flops, self.dtype, self.tag = flops, dtype, tag
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        b = torch.cuda.Event(enable_timing=True)
+        b.record()
+        prof.append((self.flops, self.dtype, self.a, b, self.tag))
+        return False
+
+
+class _NoTime:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_no_time = _NoTime()
+
+
 def _pair(v):
     v = tuple(v) if isinstance(v, (tuple, list)) else (v, v)
     assert len(v) == 2 and all(isinstance(e, int) for e in v)
@@ -95,6 +130,26 @@ def _conv2d_gradfix_build(transpose, weight_shape, stride, padding, output_paddi
         assert all(0 <= output_padding[i] < max(stride[i], dilation[i]) for i in range(2))
     common = dict(stride=stride, padding=padding, dilation=dilation, groups=groups)
 
+    def timed(input, grad_output_or_none, n_products=1):
+        """2 * N * positions * Cin * Cout * kh * kw / groups per product (forward, data gradient and weight gradient cost the same)."""
+        if prof is None or not input.is_cuda:
+            return _no_time
+        oc, icg, kh, kw = weight_shape
+        if not transpose:       # dense side = the output lattice
+            pos = (grad_output_or_none.shape[2] * grad_output_or_none.shape[3]) if grad_output_or_none is not None else None
+            macs_per_pos = oc * icg * kh * kw
+        else:                   # transposed: weight is [Cin, Cout/groups, kh, kw]; dense side = the input lattice
+            pos = input.shape[2] * input.shape[3]
+            macs_per_pos = oc * icg * kh * kw
+        if pos is None:
+            hout = (input.shape[2] + 2 * padding[0] - dilation[0] * (kh - 1) - 1) // stride[0] + 1
+            wout = (input.shape[3] + 2 * padding[1] - dilation[1] * (kw - 1) - 1) // stride[1] + 1
+            pos = hout * wout
+        kind = ('fwd', 'bwd1', 'bwd2')[n_products if grad_output_or_none is not None else 0]
+        tag = (('convT' if transpose else 'conv') + f'{kh}x{kw}s{stride[0]} w{list(weight_shape)} x{list(input.shape)} '
+               + ('nhwc' if input.dim() == 4 and input.stride(1) == 1 and input.shape[1] > 1 else 'nchw') + ' ' + kind)
+        return _Timed(2.0 * input.shape[0] * pos * macs_per_pos * n_products, input.dtype, tag)
+
     def opposite_output_padding(input_shape, output_shape):
         """output_padding that makes the opposite op reproduce input_shape exactly."""
         if transpose:
@@ -107,10 +162,11 @@ def _conv2d_gradfix_build(transpose, weight_shape, stride, padding, output_paddi
         def forward(ctx, input, weight, bias):
             assert weight.shape == weight_shape
             ctx.save_for_backward(input, weight)
-            if not transpose:
-                return torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, **common)
-            return torch.nn.functional.conv_transpose2d(input=input, weight=weight, bias=bias,
-                                                        output_padding=output_padding, **common)
+            with timed(input, None):
+                if not transpose:
+                    return torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, **common)
+                return torch.nn.functional.conv_transpose2d(input=input, weight=weight, bias=bias,
+                                                            output_padding=output_padding, **common)
 
         @staticmethod
         def backward(ctx, grad_output):
@@ -121,9 +177,10 @@ def _conv2d_gradfix_build(transpose, weight_shape, stride, padding, output_paddi
                 # two differentiable ops below, without two more python autograd nodes per convolution)
                 need_w = bool(ctx.needs_input_grad[1] and not weight_gradients_disabled)
                 if ctx.needs_input_grad[0] or need_w:
-                    grad_input, grad_weight, _ = torch.ops.aten.convolution_backward(
-                        grad_output, input, weight, None, list(stride), list(padding), list(dilation), transpose,
-                        list(output_padding), groups, [bool(ctx.needs_input_grad[0]), need_w, False])
+                    with timed(input, grad_output, int(bool(ctx.needs_input_grad[0])) + int(need_w)):
+                        grad_input, grad_weight, _ = torch.ops.aten.convolution_backward(
+                            grad_output, input, weight, None, list(stride), list(padding), list(dilation), transpose,
+                            list(output_padding), groups, [bool(ctx.needs_input_grad[0]), need_w, False])
                     if not ctx.needs_input_grad[0]:
                         grad_input = None
                     if not need_w:
@@ -148,9 +205,10 @@ def _conv2d_gradfix_build(transpose, weight_shape, stride, padding, output_paddi
         def forward(ctx, grad_output, input):
             ctx.save_for_backward(grad_output, input)
             dummy_w = torch.empty(weight_shape, dtype=input.dtype, device=input.device)
-            _, grad_weight, _ = torch.ops.aten.convolution_backward(
-                grad_output, input, dummy_w, None, list(stride), list(padding), list(dilation), transpose,
-                list(output_padding), groups, [False, True, False])
+            with timed(input, grad_output):
+                _, grad_weight, _ = torch.ops.aten.convolution_backward(
+                    grad_output, input, dummy_w, None, list(stride), list(padding), list(dilation), transpose,
+                    list(output_padding), groups, [False, True, False])
             assert grad_weight.shape == weight_shape
             return grad_weight
 

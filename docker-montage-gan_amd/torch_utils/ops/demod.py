@@ -18,16 +18,26 @@ def _composite(weight, styles):
     return (styles.square() @ wsq.t() + 1e-8).rsqrt()       # [N,O]
 
 
+def _dense(weight):
+    """(tensor, channels_last flag): the weight as the kernels read it -- in place when it is contiguous or channels-last
+    (the layout of the reduced-precision blocks' parameters), a contiguous copy otherwise."""
+    if weight.is_contiguous():
+        return weight, 0
+    if weight.is_contiguous(memory_format=torch.channels_last):
+        return weight, 1
+    return weight.contiguous(), 0
+
+
 class _Demod(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, styles):
-        w, s = weight.contiguous(), styles.contiguous()
+        (w, cl), s = _dense(weight), styles.contiguous()
         oc, ic, kh, kw = w.shape
         n = s.shape[0]
         d = torch.empty([n, oc], dtype=torch.float32, device=w.device)
         wsq = torch.empty([oc, ic], dtype=torch.float32, device=w.device)
         with native.guard(w.device):
-            native.check(native.lib().mg_demod_fwd(w.data_ptr(), s.data_ptr(), d.data_ptr(), wsq.data_ptr(), n, oc, ic, kh * kw,
+            native.check(native.lib().mg_demod_fwd(w.data_ptr(), s.data_ptr(), d.data_ptr(), wsq.data_ptr(), n, oc, ic, kh * kw, cl,
                                                    native.stream_ptr(w.device)))
         ctx.save_for_backward(weight, styles, d, wsq)
         return d
@@ -44,14 +54,14 @@ class _Demod(torch.autograd.Function):
             dw = (2 * weight * (t.t() @ styles.square())[:, :, None, None]) if need_w else None
             ds = (2 * styles * (t @ wsq_)) if need_s else None
             return dw, ds
-        w, s, g = weight.contiguous(), styles.contiguous(), g.contiguous()
+        (w, cl), s, g = _dense(weight), styles.contiguous(), g.contiguous()
         oc, ic, kh, kw = w.shape
         n = s.shape[0]
-        dw = torch.empty_like(w) if need_w else None
+        dw = torch.empty_like(w) if need_w else None           # same dense layout as w (preserve_format)
         ds = torch.empty_like(s) if need_s else None
         with native.guard(w.device):
             native.check(native.lib().mg_demod_bwd(w.data_ptr(), s.data_ptr(), d.data_ptr(), wsq.data_ptr(), g.data_ptr(),
-                                                   ds.data_ptr() if need_s else None, dw.data_ptr() if need_w else None, n, oc, ic, kh * kw,
+                                                   ds.data_ptr() if need_s else None, dw.data_ptr() if need_w else None, n, oc, ic, kh * kw, cl,
                                                    native.stream_ptr(w.device)))
         return dw, ds
 

@@ -3,14 +3,17 @@
 because the losses call ``report`` on the step path and ADA reads 'Loss/signs/real' through a
 Collector.  One all_reduce of [n_names, 3] float64 per ``Collector.update()`` (:262), as upstream.
 
-Host-overhead note for MI355X: ``report`` is three reductions + a stack per call upstream.  Here the
-three moments come from ONE small matmul-free expression and the accumulate is a single in-place add,
-and ``enabled = False`` turns reporting into a no-op for throughput measurements that do not need it.
+MI355X note: ``report`` is a flatten, a cast, three reductions, a stack, a cast and an add per call upstream (~75 calls per
+training step).  For GPU tensors the three moments are accumulated into the float64 counter by ONE native launch
+(csrc/stats.hip, ``mg_stats_accumulate``); CPU tensors and python scalars take the aten expression.
+``enabled = False`` turns reporting into a no-op.
 """
 import re
 
 import numpy as np
 import torch
+
+from . import native
 
 enabled = True
 _num_moments = 3
@@ -21,6 +24,7 @@ _sync_device = None
 _sync_called = False
 _counters = dict()      # name -> device -> float64[3] running [count, sum, sum of squares]
 _cumulative = dict()    # name -> float64[3] on the CPU, updated by _sync()
+_native_dtypes = (torch.float32, torch.float16, torch.bfloat16)
 
 
 def init_multiprocessing(rank, sync_device):
@@ -36,6 +40,18 @@ def report(name, value):
         return value
     elems = torch.as_tensor(value)
     if elems.numel() == 0:
+        return value
+    if elems.is_cuda and elems.dtype in _native_dtypes:
+        # MI355X path: ONE native launch adds [count, sum, sum of squares] to the float64 counter (csrc/stats.hip)
+        x = elems.detach()
+        if not x.is_contiguous():
+            x = x.contiguous()
+        slot = _counters[name].get(x.device)
+        if slot is None:
+            slot = _counters[name][x.device] = torch.zeros([_num_moments], dtype=_counter_dtype, device=x.device)
+        with native.guard(x.device):
+            native.check(native.lib().mg_stats_accumulate(x.data_ptr(), native.dtype_code(x.dtype), x.numel(), slot.data_ptr(),
+                                                          native.stream_ptr(x.device)))
         return value
     elems = elems.detach().flatten().to(_reduce_dtype)
     moments = torch.stack([elems.new_full([], float(elems.numel())), elems.sum(), elems.square().sum()]).to(_counter_dtype)

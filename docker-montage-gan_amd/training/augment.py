@@ -25,6 +25,7 @@ import torch
 
 from ..torch_utils import misc
 from ..torch_utils.ops import conv2d_gradfix
+from ..torch_utils.ops import ada_params
 from ..torch_utils.ops import affine_warp
 from ..torch_utils.ops import channel_mix
 from ..torch_utils.ops import grid_sample_gradfix  # noqa: F401  (reference import; affine_warp falls back to it)
@@ -32,7 +33,33 @@ from ..torch_utils.ops import upfirdn2d
 
 fixed_margin = False          # True: never read the padding margin back to the host (see module docstring)
 side_stream_margin = False    # True: compute transform parameters + margin on a side stream, wait only for that
+fused_params = True            # GPU, no debug_percentile: transform parameters from ONE native launch (ops/ada_params.py)
 _side_streams = dict()
+
+
+class _Draws:
+    """Where the pipe's random numbers come from: fresh draws in the reference's order and shapes (tables None), or the
+    columns of two pre-drawn tables U [n,nu] (uniform) / Z [n,nz] (normal), consumed left to right -- the layout
+    ``ops.ada_params`` documents."""
+
+    def __init__(self, device, U=None, Z=None):
+        self.device, self.U, self.Z, self.iu, self.iz = device, U, Z, 0, 0
+
+    def _take(self, table, pos, shape):
+        k = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        return table[:, pos:pos + k].reshape(shape), pos + k
+
+    def rand(self, *shape):
+        if self.U is None:
+            return torch.rand(list(shape), device=self.device)
+        out, self.iu = self._take(self.U, self.iu, list(shape))
+        return out
+
+    def randn(self, *shape):
+        if self.Z is None:
+            return torch.randn(list(shape), device=self.device)
+        out, self.iz = self._take(self.Z, self.iz, list(shape))
+        return out
 
 # Orthogonal wavelet low-pass filters (Daubechies / symlets), as tabulated in PyWavelets.
 wavelets = {
@@ -137,61 +164,62 @@ class AugmentPipe(torch.nn.Module):
 
     # one "maybe apply" draw: value where rand < prob else neutral; debug_percentile overrides both draws
     @staticmethod
-    def _gate(value, prob, neutral, shape, device):
-        return torch.where(torch.rand(shape, device=device) < prob, value, neutral)
+    def _gate(value, prob, neutral, shape, draws):
+        return torch.where(draws.rand(*shape) < prob, value, neutral)
 
-    def _geometric_params(self, n, height, width, dev, dp):
+    def _geometric_params(self, n, height, width, dev, dp, draws=None):
         """Random draws of the blit/geometric stage -> (G_inv [n,3,3] or the identity object, I_3, margin [4] or None)."""
-        rand, randn = (lambda *s: torch.rand(list(s), device=dev)), (lambda *s: torch.randn(list(s), device=dev))
+        draws = draws if draws is not None else _Draws(dev)
+        rand, randn = draws.rand, draws.randn
         # ---- pixel blitting + general geometric transforms, accumulated as one inverse matrix ----
         I_3 = torch.eye(3, device=dev)
         G_inv = I_3
         if self.xflip > 0:
             i = torch.floor(rand(n) * 2)
-            i = self._gate(i, self.xflip * self.p, torch.zeros_like(i), [n], dev)
+            i = self._gate(i, self.xflip * self.p, torch.zeros_like(i), [n], draws)
             if dp is not None:
                 i = torch.full_like(i, torch.floor(dp * 2))
             G_inv = G_inv @ scale2d_inv(1 - 2 * i, 1)
         if self.rotate90 > 0:
             i = torch.floor(rand(n) * 4)
-            i = self._gate(i, self.rotate90 * self.p, torch.zeros_like(i), [n], dev)
+            i = self._gate(i, self.rotate90 * self.p, torch.zeros_like(i), [n], draws)
             if dp is not None:
                 i = torch.full_like(i, torch.floor(dp * 4))
             G_inv = G_inv @ rotate2d_inv(-np.pi / 2 * i)
         if self.xint > 0:
             t = (rand(n, 2) * 2 - 1) * self.xint_max
-            t = self._gate(t, self.xint * self.p, torch.zeros_like(t), [n, 1], dev)
+            t = self._gate(t, self.xint * self.p, torch.zeros_like(t), [n, 1], draws)
             if dp is not None:
                 t = torch.full_like(t, (dp * 2 - 1) * self.xint_max)
             G_inv = G_inv @ translate2d_inv(torch.round(t[:, 0] * width), torch.round(t[:, 1] * height))
         if self.scale > 0:
             s = torch.exp2(randn(n) * self.scale_std)
-            s = self._gate(s, self.scale * self.p, torch.ones_like(s), [n], dev)
+            s = self._gate(s, self.scale * self.p, torch.ones_like(s), [n], draws)
             if dp is not None:
                 s = torch.full_like(s, torch.exp2(torch.erfinv(dp * 2 - 1) * self.scale_std))
             G_inv = G_inv @ scale2d_inv(s, s)
         p_rot = 1 - torch.sqrt((1 - self.rotate * self.p).clamp(0, 1))      # P(pre OR post rotation) = p
         if self.rotate > 0:
             theta = (rand(n) * 2 - 1) * np.pi * self.rotate_max
-            theta = self._gate(theta, p_rot, torch.zeros_like(theta), [n], dev)
+            theta = self._gate(theta, p_rot, torch.zeros_like(theta), [n], draws)
             if dp is not None:
                 theta = torch.full_like(theta, (dp * 2 - 1) * np.pi * self.rotate_max)
             G_inv = G_inv @ rotate2d_inv(-theta)
         if self.aniso > 0:
             s = torch.exp2(randn(n) * self.aniso_std)
-            s = self._gate(s, self.aniso * self.p, torch.ones_like(s), [n], dev)
+            s = self._gate(s, self.aniso * self.p, torch.ones_like(s), [n], draws)
             if dp is not None:
                 s = torch.full_like(s, torch.exp2(torch.erfinv(dp * 2 - 1) * self.aniso_std))
             G_inv = G_inv @ scale2d_inv(s, 1 / s)
         if self.rotate > 0:
             theta = (rand(n) * 2 - 1) * np.pi * self.rotate_max
-            theta = self._gate(theta, p_rot, torch.zeros_like(theta), [n], dev)
+            theta = self._gate(theta, p_rot, torch.zeros_like(theta), [n], draws)
             if dp is not None:
                 theta = torch.zeros_like(theta)
             G_inv = G_inv @ rotate2d_inv(-theta)
         if self.xfrac > 0:
             t = randn(n, 2) * self.xfrac_std
-            t = self._gate(t, self.xfrac * self.p, torch.zeros_like(t), [n, 1], dev)
+            t = self._gate(t, self.xfrac * self.p, torch.zeros_like(t), [n, 1], draws)
             if dp is not None:
                 t = torch.full_like(t, torch.erfinv(dp * 2 - 1) * self.xfrac_std)
             G_inv = G_inv @ translate2d_inv(t[:, 0] * width, t[:, 1] * height)
@@ -209,82 +237,20 @@ class AugmentPipe(torch.nn.Module):
             margin = margin.max(misc.constant([0, 0] * 2, device=dev)).min(misc.constant([width - 1, height - 1] * 2, device=dev))
         return G_inv, I_3, margin
 
-    def forward(self, images, debug_percentile=None):
-        assert isinstance(images, torch.Tensor) and images.ndim == 4
-        n, ch, height, width = images.shape
-        dev = images.device
-        dp = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32, device=dev)
-        rand, randn = (lambda *s: torch.rand(list(s), device=dev)), (lambda *s: torch.randn(list(s), device=dev))
-
-        # ---- pixel blitting + general geometric transforms (one inverse matrix) and the padding they need ----
-        use_side = side_stream_margin and images.is_cuda and not fixed_margin
-        if use_side:
-            main = torch.cuda.current_stream(dev)
-            side = _side_streams.get(dev)
-            if side is None:
-                side = _side_streams[dev] = torch.cuda.Stream(device=dev, priority=-1)
-            if not hasattr(self, '_pinned_margin'):
-                self._pinned_margin = torch.empty([4], dtype=torch.int32).pin_memory()
-            with torch.cuda.stream(side):
-                G_inv, I_3, margin = self._geometric_params(n, height, width, dev, dp)
-                if margin is not None:
-                    self._pinned_margin.copy_(margin.ceil().to(torch.int32), non_blocking=True)
-                done = torch.cuda.Event()
-                done.record(side)
-            done.synchronize()                  # the host waits for the side stream only
-            main.wait_event(done)
-            if G_inv is not I_3:
-                G_inv.record_stream(main)
-        else:
-            G_inv, I_3, margin = self._geometric_params(n, height, width, dev, dp)
-        if G_inv is not I_3:
-            cx, cy = (width - 1) / 2, (height - 1) / 2
-            hz_pad = self.Hz_geom.shape[0] // 4
-            if fixed_margin:
-                mx0, my0, mx1, my1 = width - 1, height - 1, width - 1, height - 1                  # the clamp bound: no read-back
-            elif use_side:
-                mx0, my0, mx1, my1 = (int(v) for v in self._pinned_margin.tolist())             # already on the host
-            else:
-                mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().to(torch.int32).tolist())   # the one host sync
-            images = torch.nn.functional.pad(input=images, pad=[mx0, mx1, my0, my1], mode='reflect')
-            # x2 upsample with the 12-tap symlet (separable -> two native passes)
-            images = upfirdn2d.upsample2d(x=images, f=self.Hz_geom, up=2)
-            # sample on the output lattice
-            shape = [n, ch, (height + hz_pad * 2) * 2, (width + hz_pad * 2) * 2]
-            # Upstream chains six small matrix products around G_inv here (:365-375): shift by the padding, x2 scale,
-            # half-pixel shift, normalisation to [-1,1].  All of those factors are host-known constants of this call,
-            # so they are multiplied on the host (same order, float32) into ONE left and ONE right factor and uploaded
-            # without a blocking copy; per-call host->device constants would drain the launch queue four times.
-            f32 = np.float32
-
-            def T(tx, ty):
-                return np.asarray([[1, 0, tx], [0, 1, ty], [0, 0, 1]], dtype=f32)
-
-            def S(sx, sy):
-                return np.asarray([[sx, 0, 0], [0, sy, 0], [0, 0, 1]], dtype=f32)
-            left = S(2 / images.shape[3], 2 / images.shape[2]) @ (T(-0.5, -0.5) @ (S(2, 2) @ T((mx0 - mx1) / 2, (my0 - my1) / 2)))
-            right = (S(1 / 2, 1 / 2) @ T(0.5, 0.5)) @ S(1 / (2 / shape[3]), 1 / (2 / shape[2]))
-            if fixed_margin:        # host-known constants of the CONFIGURATION: cached on the device (also keeps the call recordable into a HIP graph)
-                lr = misc.constant(np.stack([left, right]), device=dev)
-            else:
-                lr = misc.upload_small(np.stack([left, right]), dev)
-            G_inv = lr[0] @ G_inv @ lr[1]
-            images = affine_warp.affine_warp(images, G_inv[:, :2, :], shape[2], shape[3])     # affine_grid + grid_sample, one pass
-            # back down, cropping the filter margin
-            images = upfirdn2d.downsample2d(x=images, f=self.Hz_geom, down=2, padding=-hz_pad * 2, flip_filter=True)
-
-        # ---- colour transforms, accumulated as one 4x4 matrix on (r, g, b, 1) ----
-        I_4 = torch.eye(4, device=dev)
+    def _color_matrix(self, n, ch, dev, dp, I_4, draws=None):
+        """Random draws of the colour stage -> C [n,4,4] acting on (r, g, b, 1), or the identity object I_4."""
+        draws = draws if draws is not None else _Draws(dev)
+        rand, randn = draws.rand, draws.randn
         C = I_4
         if self.brightness > 0:
             b = randn(n) * self.brightness_std
-            b = self._gate(b, self.brightness * self.p, torch.zeros_like(b), [n], dev)
+            b = self._gate(b, self.brightness * self.p, torch.zeros_like(b), [n], draws)
             if dp is not None:
                 b = torch.full_like(b, torch.erfinv(dp * 2 - 1) * self.brightness_std)
             C = translate3d(b, b, b) @ C
         if self.contrast > 0:
             c = torch.exp2(randn(n) * self.contrast_std)
-            c = self._gate(c, self.contrast * self.p, torch.ones_like(c), [n], dev)
+            c = self._gate(c, self.contrast * self.p, torch.ones_like(c), [n], draws)
             if dp is not None:
                 c = torch.full_like(c, torch.exp2(torch.erfinv(dp * 2 - 1) * self.contrast_std))
             C = scale3d(c, c, c) @ C
@@ -292,25 +258,144 @@ class AugmentPipe(torch.nn.Module):
         vv = torch.outer(v, v)
         if self.lumaflip > 0:
             i = torch.floor(rand(n, 1, 1) * 2)
-            i = self._gate(i, self.lumaflip * self.p, torch.zeros_like(i), [n, 1, 1], dev)
+            i = self._gate(i, self.lumaflip * self.p, torch.zeros_like(i), [n, 1, 1], draws)
             if dp is not None:
                 i = torch.full_like(i, torch.floor(dp * 2))
             C = (I_4 - 2 * vv * i) @ C                                             # Householder reflection
         if self.hue > 0 and ch > 1:
             theta = (rand(n) * 2 - 1) * np.pi * self.hue_max
-            theta = self._gate(theta, self.hue * self.p, torch.zeros_like(theta), [n], dev)
+            theta = self._gate(theta, self.hue * self.p, torch.zeros_like(theta), [n], draws)
             if dp is not None:
                 theta = torch.full_like(theta, (dp * 2 - 1) * np.pi * self.hue_max)
             C = rotate3d(v, theta) @ C
         if self.saturation > 0 and ch > 1:
             s = torch.exp2(randn(n, 1, 1) * self.saturation_std)
-            s = self._gate(s, self.saturation * self.p, torch.ones_like(s), [n, 1, 1], dev)
+            s = self._gate(s, self.saturation * self.p, torch.ones_like(s), [n, 1, 1], draws)
             if dp is not None:
                 s = torch.full_like(s, torch.exp2(torch.erfinv(dp * 2 - 1) * self.saturation_std))
             C = (vv + (I_4 - vv) * s) @ C
-        if C is not I_4:
+        return C
+
+    def _sampling_factors(self, n, ch, height, width, margins):
+        """The host-known factors around G_inv (upstream chains six small matrix products here, :365-375: shift by the
+        padding, x2 scale, half-pixel shift, normalisation to [-1,1]) multiplied on the host in the same order (float32)
+        into ONE left and ONE right factor; also the padded and the sampled sizes."""
+        mx0, my0, mx1, my1 = margins
+        hz_pad = self.Hz_geom.shape[0] // 4
+        pad_h, pad_w = (height + my0 + my1) * 2, (width + mx0 + mx1) * 2          # size after reflect padding and x2 upsampling
+        shape = [n, ch, (height + hz_pad * 2) * 2, (width + hz_pad * 2) * 2]
+        f32 = np.float32
+
+        def T(tx, ty):
+            return np.asarray([[1, 0, tx], [0, 1, ty], [0, 0, 1]], dtype=f32)
+
+        def S(sx, sy):
+            return np.asarray([[sx, 0, 0], [0, sy, 0], [0, 0, 1]], dtype=f32)
+        left = S(2 / pad_w, 2 / pad_h) @ (T(-0.5, -0.5) @ (S(2, 2) @ T((mx0 - mx1) / 2, (my0 - my1) / 2)))
+        right = (S(1 / 2, 1 / 2) @ T(0.5, 0.5)) @ S(1 / (2 / shape[3]), 1 / (2 / shape[2]))
+        return left, right, shape
+
+    def params_from_tables(self, U, Z, n, ch, height, width):
+        """The python formulation of the transform parameters driven by pre-drawn tables (what ``ops.ada_params`` computes in
+        one native launch): -> (G_inv or None, margin or None, C or None)."""
+        dev = U.device
+        draws = _Draws(dev, U, Z)
+        G_inv, I_3, margin = self._geometric_params(n, height, width, dev, None, draws)
+        I_4 = torch.eye(4, device=dev)
+        C = self._color_matrix(n, ch, dev, None, I_4, draws)
+        return (None if G_inv is I_3 else G_inv), margin, (None if C is I_4 else C)
+
+    def forward(self, images, debug_percentile=None):
+        assert isinstance(images, torch.Tensor) and images.ndim == 4
+        n, ch, height, width = images.shape
+        dev = images.device
+        dp = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32, device=dev)
+        draws = _Draws(dev)
+        rand, randn = draws.rand, draws.randn
+        hz_pad = self.Hz_geom.shape[0] // 4
+        # MI355X path: all ~13 random decisions of the blit / geometric / colour stages and the matrices built from them
+        # in ONE native launch from two tables of pre-drawn numbers (ops/ada_params.py).  debug_percentile and CPU tensors
+        # keep the reference's draw-by-draw formulation below (same order and shapes of draws as upstream).
+        use_native = (fused_params and images.is_cuda and dp is None and ch in (1, 3, 4)
+                      and (ada_params.has_geometric(self) or ada_params.has_color(self, ch)))
+        native_out = None
+
+        def native_params(left=None, right=None):
+            U, Z = torch.rand([n, ada_params.NU], device=dev), torch.randn([n, ada_params.NZ], device=dev)
+            return ada_params.ada_params(self, U, Z, width, height, ch, left, right)
+
+        # ---- pixel blitting + general geometric transforms (one inverse matrix) and the padding they need ----
+        use_side = side_stream_margin and images.is_cuda and not fixed_margin
+        fixed = (width - 1, height - 1, width - 1, height - 1)                   # the clamp bound: no read-back
+        theta = None
+        if use_native and fixed_margin:
+            left, right, shape = self._sampling_factors(n, ch, height, width, fixed)
+            native_out = native_params(left, right)
+            G_inv, I_3, margin, theta = native_out['G_inv'], None, native_out['margin'], native_out['theta']
+        elif use_side:
+            main = torch.cuda.current_stream(dev)
+            side = _side_streams.get(dev)
+            if side is None:
+                side = _side_streams[dev] = torch.cuda.Stream(device=dev, priority=-1)
+            if not hasattr(self, '_pinned_margin'):
+                self._pinned_margin = torch.empty([4], dtype=torch.int32).pin_memory()
+            with torch.cuda.stream(side):
+                if use_native:
+                    native_out = native_params()
+                    G_inv, I_3, margin = native_out['G_inv'], None, native_out['margin']
+                    for v in native_out.values():
+                        if v is not None:
+                            v.record_stream(main)
+                else:
+                    G_inv, I_3, margin = self._geometric_params(n, height, width, dev, dp, draws)
+                if margin is not None:
+                    self._pinned_margin.copy_(margin.ceil().to(torch.int32), non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(side)
+            done.synchronize()                  # the host waits for the side stream only
+            main.wait_event(done)
+            if G_inv is not I_3 and not use_native:
+                G_inv.record_stream(main)
+        elif use_native:
+            native_out = native_params()
+            G_inv, I_3, margin = native_out['G_inv'], None, native_out['margin']
+        else:
+            G_inv, I_3, margin = self._geometric_params(n, height, width, dev, dp, draws)
+        if G_inv is not I_3:
+            if fixed_margin:
+                margins = fixed
+            elif use_side:
+                margins = tuple(int(v) for v in self._pinned_margin.tolist())             # already on the host
+            else:
+                margins = tuple(int(v) for v in margin.ceil().to(torch.int32).tolist())   # the one host sync
+            mx0, my0, mx1, my1 = margins
+            images = torch.nn.functional.pad(input=images, pad=[mx0, mx1, my0, my1], mode='reflect')
+            # x2 upsample with the 12-tap symlet (separable -> two native passes)
+            images = upfirdn2d.upsample2d(x=images, f=self.Hz_geom, up=2)
+            if theta is None:
+                # sample on the output lattice: left @ G_inv @ right
+                left, right, shape = self._sampling_factors(n, ch, height, width, margins)
+                if fixed_margin:        # constants of the CONFIGURATION: cached on the device (keeps the call recordable into a HIP graph)
+                    lr = misc.constant(np.stack([left, right]), device=dev)
+                else:                   # depend on this call's margin: uploaded without a blocking copy
+                    lr = misc.upload_small(np.stack([left, right]), dev)
+                theta = (lr[0] @ G_inv @ lr[1])[:, :2, :]
+            images = affine_warp.affine_warp(images, theta, shape[2], shape[3])     # affine_grid + grid_sample, one pass
+            # back down, cropping the filter margin
+            images = upfirdn2d.downsample2d(x=images, f=self.Hz_geom, down=2, padding=-hz_pad * 2, flip_filter=True)
+
+        # ---- colour transforms, accumulated as one 4x4 matrix on (r, g, b, 1) ----
+        I_4 = None
+        if native_out is not None:
+            C = native_out['C']
+        else:
+            I_4 = torch.eye(4, device=dev)
+            C = self._color_matrix(n, ch, dev, dp, I_4, draws)
+        if C is not I_4 and C is not None:
             flat = images.reshape([n, ch, height * width])
-            if ch == 4:         # RGBA: colour matrix on RGB, alpha untouched (reference :403-406)
+            if ch == 4 and native_out is not None:
+                flat = channel_mix.channel_mix(flat, native_out['A4'], native_out['t4'])
+            elif ch == 4:       # RGBA: colour matrix on RGB, alpha untouched (reference :403-406)
                 A4 = I_4.repeat([n, 1, 1])
                 A4[:, :3, :3] = C[:, :3, :3]
                 flat = channel_mix.channel_mix(flat, A4, torch.nn.functional.pad(C[:, :3, 3], [0, 1]))
@@ -331,7 +416,7 @@ class AugmentPipe(torch.nn.Module):
             g = torch.ones([n, bands], device=dev)
             for i, strength in enumerate(self.imgfilter_bands):
                 t_i = torch.exp2(randn(n) * self.imgfilter_std)
-                t_i = self._gate(t_i, self.imgfilter * self.p * strength, torch.ones_like(t_i), [n], dev)
+                t_i = self._gate(t_i, self.imgfilter * self.p * strength, torch.ones_like(t_i), [n], draws)
                 if dp is not None:
                     t_i = torch.full_like(t_i, torch.exp2(torch.erfinv(dp * 2 - 1) * self.imgfilter_std)) if strength > 0 else torch.ones_like(t_i)
                 t = torch.ones([n, bands], device=dev)
@@ -349,13 +434,13 @@ class AugmentPipe(torch.nn.Module):
         # ---- image-space corruptions ----
         if self.noise > 0:
             sigma = randn(n, 1, 1, 1).abs() * self.noise_std
-            sigma = self._gate(sigma, self.noise * self.p, torch.zeros_like(sigma), [n, 1, 1, 1], dev)
+            sigma = self._gate(sigma, self.noise * self.p, torch.zeros_like(sigma), [n, 1, 1, 1], draws)
             if dp is not None:
                 sigma = torch.full_like(sigma, torch.erfinv(dp) * self.noise_std)
             images = images + randn(n, ch, height, width) * sigma
         if self.cutout > 0:
             size = torch.full([n, 2, 1, 1, 1], self.cutout_size, device=dev)
-            size = self._gate(size, self.cutout * self.p, torch.zeros_like(size), [n, 1, 1, 1, 1], dev)
+            size = self._gate(size, self.cutout * self.p, torch.zeros_like(size), [n, 1, 1, 1, 1], draws)
             center = rand(n, 2, 1, 1, 1)
             if dp is not None:
                 size = torch.full_like(size, self.cutout_size)

@@ -49,13 +49,19 @@ class StyleGAN2Loss(Loss):
 
     def run_G(self, z, c, sync):
         with misc.ddp_sync(self.G_mapping, sync):
-            ws = self._map(z, c)
             if self.style_mixing_prob > 0:
                 with torch.autograd.profiler.record_function('style_mixing'):
-                    cutoff = torch.empty([], dtype=torch.int64, device=ws.device).random_(1, ws.shape[1])
-                    cutoff = torch.where(torch.rand([], device=ws.device) < self.style_mixing_prob, cutoff,
-                                         torch.full_like(cutoff, ws.shape[1]))
-                    ws = _splice_after(ws, self._map(torch.randn_like(z), c, skip_w_avg_update=True), cutoff)
+                    # upstream maps z, then draws cutoff, the mixing coin and the partner latent, then maps the partner
+                    # (:66-72).  The mapping network draws nothing, so the same draws in the same order can come first
+                    # and both latents go through the network as ONE batch of 2N independent rows: half the launches.
+                    n, num_ws = z.shape[0], self.G_mapping.num_ws
+                    cutoff = torch.empty([], dtype=torch.int64, device=z.device).random_(1, num_ws)
+                    cutoff = torch.where(torch.rand([], device=z.device) < self.style_mixing_prob, cutoff,
+                                         torch.full_like(cutoff, num_ws))
+                    both = self._map(torch.cat([z, torch.randn_like(z)]), None if c is None else torch.cat([c, c]), w_avg_rows=n)
+                    ws = _splice_after(both[:n], both[n:], cutoff)
+            else:
+                ws = self._map(z, c)
         with misc.ddp_sync(self.G_synthesis, sync):
             ws = ws[:, :self.G_synthesis.num_ws]
             img = self.G_synthesis(ws)

@@ -194,7 +194,9 @@ class MappingNetwork(torch.nn.Module):
         layers = ([self.embed] if self.c_dim > 0 else []) + [getattr(self, f'fc{idx}') for idx in range(self.num_layers)]
         return [e for layer in layers for e in layer.prep_entries()]
 
-    def forward(self, z, c=None, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
+    def forward(self, z, c=None, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False, w_avg_rows=None):
+        """w_avg_rows: only the first that many rows feed the running average (the loss maps z and its style-mixing partner
+        in ONE call of 2N rows -- the rows are independent -- and only z's rows belong to the statistic)."""
         if self._prep is None:
             self._prep = weight_prep.Plan(self.prep_entries())
         with weight_prep.scope(self._prep):
@@ -209,7 +211,8 @@ class MappingNetwork(torch.nn.Module):
             for idx in range(self.num_layers):
                 x = getattr(self, f'fc{idx}')(x)
         if self.w_avg_beta is not None and self.training and not skip_w_avg_update:
-            self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+            xs = x.detach() if w_avg_rows is None else x.detach()[:w_avg_rows]
+            self.w_avg.copy_(xs.mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
         if self.num_ws is not None:
             x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
         if truncation_psi != 1:

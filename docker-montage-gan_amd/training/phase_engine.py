@@ -20,6 +20,9 @@ xGMI note: a ring all-reduce is per-link bound (~153 GB/s/link); the flat buffer
 large enough for RCCL's bandwidth-optimal algorithms, and one call per phase keeps latency terms off
 the step path.
 """
+import contextlib
+import gc
+
 import torch
 
 from .. import dnnlib
@@ -182,7 +185,32 @@ class Phase(dnnlib.EasyDict):
             self.opt.step()
 
 
-def run_phase(phase, accumulate, grad_sync, graphs=None, world_size=1):
+def phase_state(phase, modules=(), extra=(), flat=None, names=None):
+    """Every tensor a phase may modify, as (name, tensor, strict) triples: the parameters its optimizer owns, the
+    optimizer's state, the buffers of the modules it runs (``w_avg`` moves in every generator pass, also inside
+    discriminator phases), the flat gradient buffer and `extra` (``pl_mean``, statistics counters) -- what PhaseGraphs
+    saves and restores around the verification replays.  strict = compared tightly.  Parameters are compared loosely:
+    Adam with beta1 = 0 moves a weight by +-lr whatever the size of its gradient, so rounding noise on a near-zero
+    gradient (float atomics) flips whole steps; the gradients themselves, the moments and everything else are smooth."""
+    names = names or {}
+    out = [(names.get(id(p), f'param{i}') + str(list(p.shape)), p, False) for i, p in enumerate(phase.step_params())]
+    for i, (p, st) in enumerate(phase.opt.state.items()):
+        out += [(f'opt.{k}[{names.get(id(p), i)}]', v, True) for k, v in st.items() if isinstance(v, torch.Tensor)]
+    for mi, m in enumerate(modules):
+        if m is not None:
+            out += [(f'{type(m).__name__}{mi}.{n}', b, True) for n, b in m.named_buffers()]
+    if flat is not None:
+        out.append(('flat_gradients', flat, True))
+    out += [(f'extra{i}', t, True) for i, t in enumerate(extra) if isinstance(t, torch.Tensor)]
+    seen, uniq = set(), []
+    for name, t, strict in out:
+        if t.is_cuda and t.data_ptr() not in seen:
+            seen.add(t.data_ptr())
+            uniq.append((name, t, strict))
+    return uniq
+
+
+def run_phase(phase, accumulate, grad_sync, graphs=None, world_size=1, state_fn=None):
     """One phase of the loop (reference training_loop.py:288-317): zero_grad + requires_grad on, ``accumulate()`` (every
     accumulation round's forward/backward), requires_grad off, gradient exchange + scrub, optimizer step -- eagerly, or
     through ``graphs`` (PhaseGraphs).  With more than one rank the collective stays between two recorded halves."""
@@ -208,11 +236,11 @@ def run_phase(phase, accumulate, grad_sync, graphs=None, world_size=1):
             grad_sync.exchange(phase['_flat'])
             step()
     elif world_size == 1:
-        graphs.run(phase.name, lambda: (forward_backward(), step()), record_if=has_work)
+        graphs.run(phase.name, lambda: (forward_backward(), step()), record_if=has_work, state_fn=state_fn)
     else:
-        graphs.run((phase.name, 'fwd_bwd'), forward_backward, record_if=has_work)
+        graphs.run((phase.name, 'fwd_bwd'), forward_backward, record_if=has_work, state_fn=state_fn)
         grad_sync.exchange(phase['_flat'])
-        graphs.run((phase.name, 'step'), step, record_if=has_work)
+        graphs.run((phase.name, 'step'), step, record_if=has_work, state_fn=state_fn)
 
 
 def make_optimizer(params, opt_kwargs, device, capturable=False):
@@ -292,40 +320,84 @@ class PhaseGraphs:
     A phase of the loop (reference training_loop.py:288-317: zero_grad, forward, backward of every accumulation
     round, gradient post-processing, optimizer step) is ~1-3 thousand kernel launches whose arguments never change
     between iterations once the inputs live at fixed addresses: the host spends more time issuing them than the
-    MI355X spends executing them at small per-GPU batches.  ``run(phase, body, sync_body)`` executes ``body`` eagerly
-    the first ``warmup`` times a phase fires (solver selection, lazy state, statistics counters), then records it
-    once on a capture stream (``hipStreamBeginCapture`` through torch.cuda.graph) and from then on replays the graph:
-    one host call per phase.  Everything a body reads must be a persistent tensor that the caller refreshes in
+    MI355X spends executing them at small per-GPU batches.  ``run(key, fn)`` executes ``fn`` eagerly the first
+    ``warmup`` times (solver selection, lazy state, statistics counters), records it right after the last eager
+    execution on a capture stream (``hipStreamBeginCapture`` through torch.cuda.graph) and from then on replays the
+    graph: one host call per phase.  Everything a body reads must be a persistent tensor that the caller refreshes in
     place (reals, latents); everything it updates (parameters, Adam moments and step counters, EMA inputs, ``pl_mean``,
     ``w_avg``, statistics counters, the ADA probability ``p``) is device state updated by the recorded kernels.
 
+    ``verify=True`` (default) proves every recording before it is trusted: the state the phase may modify
+    (``state_fn()``) and the generator state are saved before the eager execution; after recording, the graph is replayed
+    TWICE from that same saved state and must land on the eager result both times (within the run-to-run spread float
+    atomics cause).  A library routine that prepares a buffer outside the captured stream -- seen on ROCm 7.2 with a
+    split-K weight-gradient GEMM whose zero fill is not recorded: first replay right, second replay accumulates onto stale
+    memory -- fails the second replay; that phase then simply stays eager (``rejected``).
+
     Multi-GPU: a collective is not recorded.  The phase is split at the gradient exchange -- graph 1 ends with the
     gradients packed into the phase's persistent flat buffer, the all-reduce runs eagerly on the same stream, graph 2
-    (scrub, scatter, optimizer step) follows.
-    All graphs share one memory pool: they replay strictly one after another on one stream.
+    (scrub, optimizer step) follows.
+    Memory: every graph keeps its own private pool by default (``share_pool=False``): a graph's scratch buffers are then
+    written by that graph alone, which is what makes two back-to-back verification replays representative of every later
+    replay; sized for 288 GB of HBM3E (the 36 phase graphs of the 8-layer step at batch 32 hold well under half of it).
+    ``share_pool=True`` lets the graphs reuse each other's scratch memory (they replay strictly one after another).
     """
 
-    def __init__(self, device, warmup=1):
+    def __init__(self, device, warmup=1, verify=True, verify_tol=0.02, verify_tol_loose=0.5, share_pool=False):
         self.device = torch.device(device)
-        self.warmup = warmup
+        self.warmup, self.verify, self.verify_tol, self.verify_tol_loose = warmup, verify, verify_tol, verify_tol_loose
         self._seen = dict()         # key -> eager executions so far
         self._graphs = dict()       # key -> torch.cuda.CUDAGraph
+        self.rejected = dict()      # key -> reason (recorded, failed verification: stays eager)
+        self._discarded = []
+        self.share_pool = share_pool
         self._pool = None
-        self._stream = None
+        self.stream = torch.cuda.Stream(device=self.device)
         self.captured = 0
         self.replays = 0
 
+    @contextlib.contextmanager
+    def stream_scope(self):
+        """Everything the loop does while graphs are in use -- eager warm-up executions, recordings, replays, the phases
+        that stay eager -- runs on ONE side stream, the recording stream.  Autograd keys each parameter's gradient
+        accumulator to the stream it was created on; an accumulator that an earlier eager pass created on the default
+        stream and that is still alive when a phase is recorded would do its work on the default stream, i.e. OUTSIDE the
+        recording: the replayed graph then never writes those gradients (torch warns "the AccumulateGrad node's stream
+        does not match ... break CUDA graph capture").  With a single stream for all of it there is nothing to mismatch."""
+        outer = torch.cuda.current_stream(self.device)
+        if outer == self.stream:
+            yield
+            return
+        self.stream.wait_stream(outer)
+        with torch.cuda.stream(self.stream):
+            yield
+        outer.wait_stream(self.stream)
+
     def _capture(self, fn):
-        if self._stream is None:
-            self._stream = torch.cuda.Stream(device=self.device)
-            self._pool = torch.cuda.graph_pool_handle()
+        gc.collect()            # autograd graphs of earlier eager passes that only a reference cycle keeps alive
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self._pool, stream=self._stream):
-            fn()
-        self.captured += 1
+        if self.share_pool:
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g, pool=self._pool, stream=self.stream):
+                fn()
+        else:
+            with torch.cuda.graph(g, stream=self.stream):
+                fn()
         return g
 
-    def run(self, key, fn, record_if=None):
+    @staticmethod
+    def _deviation(after, got, before):
+        """|after - got| / |after - before| per tensor (float64 accumulation).  Non-finite values count as equal when both
+        sides hold the same one at the same place (the R1 penalty of a fully transparent pixel is NaN upstream as well)."""
+        big = 3.0e38
+        a, g, b = (torch.nan_to_num(t.double(), nan=big, posinf=big / 2, neginf=-big / 2) for t in (after, got, before))
+        num, den = float((a - g).square().sum()), float((a - b).square().sum())
+        if num != num or num == float('inf'):
+            return float('inf'), num, den
+        return (num, den)[0] ** 0.5 / max(den, 1e-60) ** 0.5 if num > 0 else 0.0, num, den
+
+    def run(self, key, fn, record_if=None, state_fn=None):
         """Execute fn(): eagerly the first `warmup` times, through its graph afterwards.  The recording is made right
         after the last eager execution (recording executes nothing on the device), so a phase that fires rarely --
         Dreg, every 16th iteration -- is replayed from its second firing on instead of being recorded in the middle
@@ -335,9 +407,58 @@ class PhaseGraphs:
             g.replay()
             self.replays += 1
             return True
+        if key in self.rejected:
+            fn()
+            return False
         n = self._seen.get(key, 0) + 1
         self._seen[key] = n
+        last = n >= self.warmup
+        check = last and self.verify and state_fn is not None
+        if check:
+            before0 = {t.data_ptr(): t.detach().clone() for _, t, _ in state_fn()}          # keyed by storage address
+            rng_before = torch.cuda.get_rng_state(self.device)
         fn()
-        if n >= self.warmup and (record_if is None or record_if()):
-            self._graphs[key] = self._capture(fn)
+        if not (last and (record_if is None or record_if())):
+            return False
+        if check:
+            torch.cuda.synchronize(self.device)
+            # state created lazily inside fn (Adam moments and step counters, statistics counters) started from zero
+            entries = state_fn()
+            state = [t.detach() for _, t, _ in entries]
+            before = [before0[t.data_ptr()] if t.data_ptr() in before0 else torch.zeros_like(t) for t in state]
+            after = [t.clone() for t in state]
+            rng_after = torch.cuda.get_rng_state(self.device)
+        g = self._capture(fn)
+        if check:
+            worst, why = 0.0, ''
+            for rep in range(2):
+                torch._foreach_copy_(state, before)
+                torch.cuda.set_rng_state(rng_before, self.device)
+                g.replay()
+                torch.cuda.synchronize(self.device)
+                groups = {True: [0.0, 0.0], False: [0.0, 0.0]}
+                offenders = []
+                for (name, _, strict), a_, s_, b_ in zip(entries, after, state, before):
+                    dev, num, den = self._deviation(a_, s_, b_)
+                    groups[strict][0] += num
+                    groups[strict][1] += den
+                    if dev > (self.verify_tol if strict else self.verify_tol_loose):
+                        offenders.append((dev, name))
+                for strict, (num, den) in groups.items():
+                    tol = self.verify_tol if strict else self.verify_tol_loose
+                    dev = float('inf') if (num != num or num == float('inf')) else (num / max(den, 1e-60)) ** 0.5 if num > 0 else 0.0
+                    if dev > tol and dev / tol > worst:
+                        worst = dev / tol
+                        top = ', '.join(f'{n} {d:.3g}' for d, n in sorted(offenders, reverse=True)[:4])
+                        why = (f'replay {rep + 1} deviates from the eager execution by {dev:.3g} of the update on the '
+                               f'{"strictly" if strict else "loosely"} compared state (tolerance {tol}); worst: {top}')
+            torch._foreach_copy_(state, after)                  # continue from the eager result
+            torch.cuda.set_rng_state(rng_after, self.device)
+            if why:
+                self.rejected[key] = why
+                if self.share_pool:
+                    self._discarded.append(g)       # keeps the shared pool's use count above zero; its blocks are reused by later recordings
+                return False
+        self._graphs[key] = g
+        self.captured += 1
         return False

@@ -53,7 +53,7 @@ class Trainer:
                  G_kwargs=None, D_kwargs=None, G_opt_kwargs=None, D_opt_kwargs=None, augment_kwargs=None, loss_kwargs=None,
                  batch_size=4, batch_gpu=4, ema_kimg=10, ema_rampup=None, G_reg_interval=4, D_reg_interval=16, augment_p=0,
                  ada_target=None, ada_interval=4, ada_kimg=500, cudnn_benchmark=True, allow_tf32=False, resident_batches=None,
-                 graphs=False, graph_warmup=1, grad_wire_dtype=None, **_unused):
+                 graphs=False, graph_warmup=1, graph_verify=True, grad_wire_dtype=None, **_unused):
         self.rank, self.num_gpus = rank, num_gpus
         self.device = device = torch.device('cuda', rank) if device is None else torch.device(device)
         self.batch_size, self.batch_gpu = batch_size, batch_gpu
@@ -89,7 +89,7 @@ class Trainer:
             phase_engine.broadcast_module_state([self.G, self.D, self.G_ema])
         self.grad_sync = phase_engine.GradSync(world_size=num_gpus, wire_dtype=grad_wire_dtype)
         # graphs=True: phases are recorded into HIP graphs after `graph_warmup` eager executions (phase_engine.PhaseGraphs)
-        self.graphs = phase_engine.PhaseGraphs(device, warmup=graph_warmup) if graphs and device.type == 'cuda' else None
+        self.graphs = phase_engine.PhaseGraphs(device, warmup=graph_warmup, verify=graph_verify) if graphs and device.type == 'cuda' else None
         self._static = None
         self.loss = dnnlib.util.construct_class_by_name(device=device, G_mapping=self.G.mapping, G_synthesis=self.G.synthesis,
                                                         D=self.D, augment_pipe=self.augment_pipe, **loss_kwargs)
@@ -140,6 +140,13 @@ class Trainer:
         return st
 
     def run_iteration(self):
+        """One loop iteration; with phase graphs everything runs on the recording stream (PhaseGraphs.stream_scope)."""
+        if self.graphs is None:
+            return self._run_iteration()
+        with self.graphs.stream_scope():
+            return self._run_iteration()
+
+    def _run_iteration(self):
         """One loop iteration (reference :277-337)."""
         device = self.device
         with torch.autograd.profiler.record_function('data_fetch'):
@@ -155,7 +162,10 @@ class Trainer:
                 for round_idx, (real_img, real_c, gen_z, gen_c) in enumerate(zip(st.img_rounds, st.c_rounds, phase_gen_z, phase_gen_c)):
                     self.loss.accumulate_gradients(phase=phase.name, real_img=real_img, real_c=real_c, gen_z=gen_z, gen_c=gen_c,
                                                    sync=(round_idx == rounds - 1), gain=phase.interval)
-            phase_engine.run_phase(phase, accumulate, self.grad_sync, self.graphs, self.num_gpus)
+            phase_engine.run_phase(phase, accumulate, self.grad_sync, self.graphs, self.num_gpus,
+                                   state_fn=lambda phase=phase: phase_engine.phase_state(
+                                       phase, [self.G, self.D], [self.loss.pl_mean] + [t for d in training_stats._counters.values() for t in d.values()],
+                                       flat=self.grad_sync._flat.get(id(phase.opt))))
             if phase.end_event is not None:
                 phase.end_event.record(torch.cuda.current_stream(device))
                 phase['_timed'] = True

@@ -71,6 +71,8 @@ enum {
     MG_K_CHANNEL_MIX = 15,
     MG_K_DEMOD = 16,
     MG_K_LINEAR = 17,
+    MG_K_STATS = 18,
+    MG_K_ADA_PARAMS = 19,
     MG_K_COUNT = 24
 };
 
@@ -179,11 +181,13 @@ int mg_bwd_fused_nhwc(const void* dy, const void* yref, const void* x, const flo
 /* ---- demodulation coefficients ---------------------------------------------------
  * d[n,o] = rsqrt(sum_i s[n,i]^2 * wsq[o,i] + 1e-8), wsq[o,i] = sum_k w[o,i,k]^2 -- the demodulation of
  * modulated_conv2d (training/networks.py:76-77) for the shared-weight path, float32.
- * w [O,I,kk] contiguous, s [N,I], d [N,O], wsq [O,I] (written by fwd, read by bwd).
- * mg_demod_bwd: g = d(loss)/d(d) [N,O]; writes ds [N,I] and / or dw [O,I,kk] (either may be NULL).          */
-int mg_demod_fwd(const float* w, const float* s, float* d, float* wsq, int32_t n, int32_t oc, int32_t ic, int32_t kk, void* stream);
+ * w dense: [O,I,kk] (channels_last = 0) or [O,kk,I] (channels_last = 1, torch.channels_last of [O,I,kh,kw]);
+ * s [N,I], d [N,O], wsq [O,I] (written by fwd, read by bwd).
+ * mg_demod_bwd: g = d(loss)/d(d) [N,O]; writes ds [N,I] and / or dw in w's layout (either may be NULL).       */
+int mg_demod_fwd(const float* w, const float* s, float* d, float* wsq, int32_t n, int32_t oc, int32_t ic, int32_t kk,
+                 int32_t channels_last, void* stream);
 int mg_demod_bwd(const float* w, const float* s, const float* d, const float* wsq, const float* g, float* ds, float* dw,
-                 int32_t n, int32_t oc, int32_t ic, int32_t kk, void* stream);
+                 int32_t n, int32_t oc, int32_t ic, int32_t kk, int32_t channels_last, void* stream);
 
 /* ---- small-batch fully connected layer --------------------------------------------
  * y[M,O] = x[M,I] @ w[O,I]^T (+ b[O]), float32, M <= 64: FullyConnectedLayer (training/networks.py:104-133:
@@ -208,6 +212,25 @@ int mg_affine_warp_bwd(const void* dy, const float* theta, void* dx, int dtype, 
                        int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w, void* stream);
 int mg_channel_mix(const void* x, const float* A, const float* t, void* y, int dtype, int32_t n, int32_t c,
                    int64_t hw, void* stream);
+
+/*
+ * mg_stats_accumulate: counter[0..2] += [n, sum(x), sum(x^2)] for a dense tensor of n elements (float32 / float16 / bfloat16),
+ * float64 atomics -- what training_stats.report() does with six aten kernels per reported value
+ * (reference montage_gan/torch_utils/training_stats.py:58-101).
+ */
+int mg_stats_accumulate(const void* x, int dtype, int64_t n, double* counter, void* stream);
+
+/*
+ * mg_ada_params: the per-sample transform parameters of AugmentPipe (reference montage_gan/training/augment.py:236-330 geometric
+ * stage, :380-420 colour stage) from pre-drawn random tables U [n,nu] (uniform) and Z [n,nz] (normal) and the device scalar p:
+ *   Ginv [n,3,3]   inverse geometric matrix (NULL: geometric stage off);  margin [4] reflect-padding reach x0,y0,x1,y1 (float, not yet ceil'ed)
+ *   theta [n,2,3]  (left @ Ginv @ right)[:2] when cfg carries the two host-known factors (has_lr), else NULL
+ *   Cmat [n,4,4]   colour matrix (NULL: colour stage off);  A4 [n,4,4], t4 [n,4]  its RGBA form for mg_channel_mix (optional)
+ * cfg: 44 floats -- 21 probabilities / strengths in constructor order of the enabled transforms, width, height, hz_pad, channels,
+ * has_lr, left[9], right[9] (see torch_utils/ops/ada_params.py).  One launch instead of ~200 aten launches per call.
+ */
+int mg_ada_params(const float* U, const float* Z, const float* p, int32_t n, int32_t nu, int32_t nz, const float* cfg, int32_t ncfg,
+                  float* Ginv, float* margin, float* theta, float* Cmat, float* A4, float* t4, void* stream);
 
 /* ---- alpha composite -------------------------------------------------------
  * x: [B, L, 4, H, W] contiguous (RGB + alpha, values nominally in [0,1]);

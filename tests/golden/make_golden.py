@@ -446,6 +446,14 @@ def gen_augment():
     save('augment', arrays, dict(cases=cases))
 
 
+def stn_dither():
+    """[1,1,1,128,128] deterministic ripple (a formula, not stored): without it the 8x8 constant blocks of the STN test image
+    make every MaxPool window an exact tie, and which element of a tie receives the gradient is implementation-defined."""
+    h = torch.arange(128, dtype=torch.float32).reshape(128, 1)
+    w = torch.arange(128, dtype=torch.float32).reshape(1, 128)
+    return (0.02 * torch.sin(0.37 * h + 0.71 * w + 0.5) * torch.cos(0.23 * h - 0.11 * w)).reshape(1, 1, 1, 128, 128)
+
+
 def gen_aio():
     """The global half of the all-in-one step (custom/loss_aio.py:182-341) and the STN end to end
     (fukuwarai/networks.py:148-258), on toy networks whose weights are stored with the vectors:
@@ -479,13 +487,13 @@ def gen_aio():
             stn.fc_loc[2].bias.normal_(0, 0.2)
         _sd(f'stn{ci}', stn, arrays)
         x = torch.rand([2, 3, 4, 16, 16], generator=g).repeat_interleave(8, 3).repeat_interleave(8, 4)      # blocky: compresses well
-        x = (x * (1 - lo) + lo).contiguous()
+        x = (x * (1 - lo) + lo).contiguous() + stn_dither()           # the dither breaks the exact ties a blocky image gives MaxPool
         xr = x.clone().requires_grad_(True)
         y, th = stn(xr)
         dy = torch.randn([2, 3, 4, 16, 16], generator=g).repeat_interleave(8, 3).repeat_interleave(8, 4).contiguous()
         params = list(stn.parameters())
         grads = torch.autograd.grad([y], [xr] + params, [dy])
-        arrays[f'stn{ci}_x16'], arrays[f'stn{ci}_dy16'] = x[..., ::8, ::8], dy[..., ::8, ::8]
+        arrays[f'stn{ci}_x16'], arrays[f'stn{ci}_dy16'] = (x - stn_dither())[..., ::8, ::8], dy[..., ::8, ::8]
         arrays[f'stn{ci}_theta'], arrays[f'stn{ci}_y'], arrays[f'stn{ci}_dx'] = th.detach(), y.detach().to(torch.float16), grads[0].to(torch.float16)
         arrays[f'stn{ci}_y_sum'], arrays[f'stn{ci}_dx_sum'] = y.detach().double().sum(), grads[0].double().sum()
         arrays[f'stn{ci}_dparam_sum'] = np.asarray([float(t.double().sum()) for t in grads[1:]])
@@ -520,6 +528,12 @@ def gen_aio():
     real16[:, :, 3] = (real16[:, :, 3] > 0.5).float()
     arrays['aio_real16'] = real16
     real = (real16.repeat_interleave(16, 3).repeat_interleave(16, 4) * 2 - 1).contiguous()         # [B,L,4,256,256] in [-1,1]
+    # the deterministic variants use alpha in [0.05, 1]: a pixel that is fully transparent in every layer makes the
+    # composite's second-order gradient 0/0 = NaN upstream (then EVERY gradient of global_Dreg is NaN and is scrubbed to 0)
+    real16_det = real16.clone()
+    real16_det[:, :, 3] = 0.05 + 0.95 * torch.rand([2, L, 16, 16], generator=g)
+    arrays['aio_real16_det'] = real16_det
+    real_det = (real16_det.repeat_interleave(16, 3).repeat_interleave(16, 4) * 2 - 1).contiguous()
     sd0 = {k: {n: v.clone() for n, v in m.state_dict().items()} for k, m in mods.items()}
     runs = [(phase, False) for phase in ['global_Gmain', 'global_Greg', 'global_Dmain', 'global_Dreg', 'global_Gboth', 'global_Dboth']]
     # deterministic variants (no style mixing, noise strength 0): comparable on a device whose generator differs
@@ -546,7 +560,7 @@ def gen_aio():
         torch.manual_seed(3000 + pi)
         gen_z = torch.randn([2, 16])
         arrays[f'g{pi}_gen_z'] = gen_z
-        loss.accumulate_gradients(phase=phase, real_blchw=real, real_list_of_bchw=None, gen_z=gen_z, sync=True, gain=1.5)
+        loss.accumulate_gradients(phase=phase, real_blchw=real_det if det else real, real_list_of_bchw=None, gen_z=gen_z, sync=True, gain=1.5)
         for m in on:
             m.requires_grad_(False)
         gnames, sums, abss = [], [], []

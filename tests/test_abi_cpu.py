@@ -55,3 +55,37 @@ def test_gpu_tensor_without_library_raises(monkeypatch):
     monkeypatch.setattr(native, 'LIB_PATH', '/nonexistent/libmontage_hip.so')
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         native.lib()
+
+
+def test_torch_plugin_shim_builds_loads_and_validates_like_the_reference():
+    """csrc/torch_plugin.cpp -- the torch.utils.cpp_extension (pybind11 / ATen) shim over the C ABI: builds in-tree, exposes the
+    reference's two plugin functions through custom_ops.get_plugin, and raises the reference's TORCH_CHECK messages
+    (upfirdn2d.cpp:19-28, bias_act.cpp:35-51) before anything touches a device."""
+    import importlib
+    import pytest
+    import torch
+    pkg = load_pkg()
+    native = pkg.native
+    native.build_torch_plugin()
+    assert os.path.exists(native.torch_plugin_path()) and native.torch_plugin().abi_version() == 1
+    co = importlib.import_module('docker-montage-gan_amd.torch_utils.custom_ops')
+    co._cached_plugins.clear()
+    old = co.verbosity
+    co.verbosity = 'none'
+    try:
+        up = co.get_plugin('upfirdn2d_plugin', sources=['upfirdn2d.cpp', 'upfirdn2d.cu'], extra_cuda_cflags=['--use_fast_math'])
+        ba = co.get_plugin('bias_act_plugin', sources=['bias_act.cpp', 'bias_act.cu'], extra_cuda_cflags=['--use_fast_math'])
+        assert co.get_plugin('upfirdn2d_plugin') is up
+        with pytest.raises(RuntimeError, match='unknown plugin'):
+            co.get_plugin('nonexistent_plugin')
+    finally:
+        co.verbosity = old
+    assert type(up).__name__ == '_TorchPlugin' and 'built-in' in repr(up.upfirdn2d)         # the pybind functions, not the ctypes classes
+    null = torch.empty([0])
+    with pytest.raises(RuntimeError, match='x must reside on CUDA device'):
+        up.upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(2, 2), 1, 1, 1, 1, 0, 0, 0, 0, False, 1.0)
+    with pytest.raises(RuntimeError, match='x must reside on CUDA device'):
+        ba.bias_act(torch.zeros(2, 3), torch.zeros(3), null, null, null, 0, 1, 1, 0.0, 1.0, -1.0)
+    with pytest.raises(TypeError):
+        up.upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(2, 2))                               # the reference's 12-argument signature
+    co._cached_plugins.clear()

@@ -111,3 +111,44 @@ def test_fixed_margin_mode_gives_the_same_images():
             np.testing.assert_allclose(dx.numpy(), arr[f'c{c["id"]}_dx'], rtol=1e-4, atol=5e-5, err_msg=str(c))
         n += 1
     assert n == 10
+
+
+def test_table_driven_draws_reproduce_the_draw_by_draw_path():
+    """AugmentPipe.params_from_tables (the formulation ops.ada_params mirrors in one native launch) consumes its tables in
+    the order the reference-ordered code draws: record the fresh draws of one call, lay them out as tables, run again."""
+    AU = mod('training.augment')
+
+    class Recorder(AU._Draws):
+        def __init__(self, dev):
+            super().__init__(dev)
+            self.u, self.z = [], []
+
+        def rand(self, *shape):
+            v = super().rand(*shape)
+            self.u.append(v.reshape(shape[0], -1))
+            return v
+
+        def randn(self, *shape):
+            v = super().randn(*shape)
+            self.z.append(v.reshape(shape[0], -1))
+            return v
+    for spec, ch in (('bgc', 4), ('bgc', 3), ('bg', 4), ('color', 1), ('blit', 4), ('geom', 3)):
+        pipe = AU.AugmentPipe(**AU.augpipe_specs[spec])
+        pipe.p.copy_(torch.as_tensor(0.7))
+        torch.manual_seed(3)
+        n, h, w = 6, 32, 48
+        rec = Recorder(torch.device('cpu'))
+        G_inv, I_3, margin = pipe._geometric_params(n, h, w, torch.device('cpu'), None, rec)
+        I_4 = torch.eye(4)
+        C = pipe._color_matrix(n, ch, torch.device('cpu'), None, I_4, rec)
+        U = torch.cat(rec.u, dim=1) if rec.u else torch.zeros([n, 0])
+        Z = torch.cat(rec.z, dim=1) if rec.z else torch.zeros([n, 0])
+        assert U.shape[1] <= 21 and Z.shape[1] <= 7
+        if spec == 'bgc' and ch == 4:
+            assert U.shape[1] == 21 and Z.shape[1] == 7        # ops.ada_params.NU / NZ
+        G2, m2, C2 = pipe.params_from_tables(U, Z, n, ch, h, w)
+        assert (G2 is None) == (G_inv is I_3) and (C2 is None) == (C is I_4)
+        if G2 is not None:
+            assert torch.equal(G2, G_inv) and torch.equal(m2, margin)
+        if C2 is not None:
+            assert torch.equal(C2, C)

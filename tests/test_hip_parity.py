@@ -740,8 +740,12 @@ def test_demod_coefs_native_vs_oracle(native, oracle):
     D = op('demod')
     g = torch.Generator().manual_seed(9)
     k0 = native.launch_count(native.K_DEMOD)
-    for oc, ic, k, n in [(64, 128, 3, 32), (512, 512, 3, 32), (4, 64, 1, 7), (37, 100, 3, 5), (256, 512, 1, 1)]:
-        w = torch.randn([oc, ic, k, k], generator=g).to(DEV).requires_grad_(True)
+    for ci, (oc, ic, k, n) in enumerate([(64, 128, 3, 32), (512, 512, 3, 32), (4, 64, 1, 7), (37, 100, 3, 5), (256, 512, 1, 1), (64, 300, 3, 9),
+                                         (128, 64, 3, 32), (16, 8, 5, 3)]):
+        w = torch.randn([oc, ic, k, k], generator=g).to(DEV)
+        if ci >= 5:             # channels-last parameters (the reduced-precision blocks): read and written in place
+            w = w.contiguous(memory_format=torch.channels_last)
+        w.requires_grad_(True)
         s = (torch.randn([n, ic], generator=g) + 1).to(DEV).requires_grad_(True)
         d = D.demod_coefs(w, s)
         gy = torch.randn([n, oc], generator=g).to(DEV)
@@ -751,7 +755,8 @@ def test_demod_coefs_native_vs_oracle(native, oracle):
         ow, os_ = oracle.demod_coefs_bwd(wn, sn, gy.cpu().numpy())
         np.testing.assert_allclose(dw.cpu().numpy(), ow, rtol=1e-4, atol=1e-5 * np.abs(ow).max())
         np.testing.assert_allclose(ds.cpu().numpy(), os_, rtol=1e-4, atol=1e-5 * np.abs(os_).max())
-    assert native.launch_count(native.K_DEMOD) == k0 + 10           # one forward and one backward call per case
+        assert dw.stride() == w.stride()
+    assert native.launch_count(native.K_DEMOD) == k0 + 16           # one forward and one backward call per case
     # second order (path-length regularisation): gradient of a function of d's gradient
     w = torch.randn([16, 24, 3, 3], generator=g).to(DEV).requires_grad_(True)
     s = (torch.randn([4, 24], generator=g) + 1).to(DEV).requires_grad_(True)
@@ -883,3 +888,90 @@ def test_fused_backward_reductions_match_unfused(native, dtype):
                     # nearly all sums must agree closely, none may be far off
                     assert np.quantile(err, 0.98) <= tol * scale * (1 + 10 * near.mean()) and err.max() <= 0.25 * scale, \
                         f'{nm} per_sample={per_sample} {dtype}: q98 {np.quantile(err, 0.98):.3g} max {err.max():.3g} scale {scale:.3g}'
+
+
+# --------------------------------------------------------------------------------------------
+# training_stats.report on the device
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_training_stats_report_native_moments(native, dtype):
+    """mg_stats_accumulate: [count, sum, sum of squares] into the float64 counter, against the aten expression of the
+    reference (torch_utils/training_stats.py:58-101) -- small and large, contiguous and strided values, repeated reports."""
+    TS = importlib.import_module(f'{PKG}.torch_utils.training_stats')
+    TS._counters.clear()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    before = native.launch_counts()['stats']
+    want = torch.zeros([3], dtype=torch.float64)
+    vals = [torch.randn([32, 1], device=DEV, generator=g), torch.randn([1], device=DEV, generator=g), torch.randn([3, 70001], device=DEV, generator=g),
+            torch.randn([64, 8], device=DEV, generator=g)[:, ::2]]
+    for v in vals:
+        v = v.to(dtype)
+        assert TS.report('t/x', v) is v
+        f = v.detach().flatten().to(torch.float32).cpu().double()
+        want += torch.stack([torch.tensor(float(f.numel()), dtype=torch.float64), f.sum(), f.square().sum()])
+    got = TS._counters['t/x'][torch.device(DEV)].cpu()
+    assert native.launch_counts()['stats'] == before + len(vals)
+    assert float(got[0]) == float(want[0])
+    np.testing.assert_allclose(got[1:].numpy(), want[1:].numpy(), rtol=2e-6, atol=1e-3)
+    c = TS.Collector(regex='t/.*')
+    TS.report('t/x', torch.ones([4], device=DEV))
+    c.update()
+    assert c.num('t/x') == 4 and c.mean('t/x') == 1.0
+    TS._counters.clear()
+
+
+# --------------------------------------------------------------------------------------------
+# ADA transform parameters in one launch
+
+@pytest.mark.parametrize('spec,ch', [('bgc', 4), ('bgc', 3), ('bg', 4), ('color', 1), ('blit', 4), ('geom', 3), ('color', 4)])
+def test_ada_params_native_matches_python_formulation(native, spec, ch):
+    """mg_ada_params against AugmentPipe.params_from_tables (the reference-ordered python code run from the same tables):
+    G_inv, margin, theta = (left @ G_inv @ right)[:2], colour matrix and its RGBA form."""
+    AU, AP = importlib.import_module(f'{PKG}.training.augment'), op('ada_params')
+    g = torch.Generator(device=DEV).manual_seed(12)
+    for p, n, h, w in ((0.7, 32, 256, 256), (1.0, 5, 24, 40), (0.0, 3, 16, 16)):
+        pipe = AU.AugmentPipe(**AU.augpipe_specs[spec]).to(DEV)
+        pipe.p.copy_(torch.as_tensor(p))
+        U = torch.rand([n, AP.NU], device=DEV, generator=g)
+        Z = torch.randn([n, AP.NZ], device=DEV, generator=g)
+        left, right, shape = pipe._sampling_factors(n, ch, h, w, (w - 1, h - 1, w - 1, h - 1))
+        before = native.launch_counts()['ada_params']
+        out = AP.ada_params(pipe, U, Z, w, h, ch, left, right)
+        assert native.launch_counts()['ada_params'] == before + 1
+        G, m, C = pipe.params_from_tables(U, Z, n, ch, h, w)
+        assert (G is None) == (out['G_inv'] is None) and (C is None) == (out['C'] is None)
+        if G is not None:
+            np.testing.assert_allclose(out['G_inv'].cpu().numpy(), G.cpu().numpy(), rtol=2e-5, atol=2e-5 * max(h, w))
+            np.testing.assert_allclose(out['margin'].cpu().numpy(), m.cpu().numpy(), rtol=1e-5, atol=1e-3)
+            lr = torch.from_numpy(np.stack([left, right])).to(DEV)
+            want = (lr[0] @ G @ lr[1])[:, :2, :]
+            np.testing.assert_allclose(out['theta'].cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5)
+        if C is not None:
+            np.testing.assert_allclose(out['C'].cpu().numpy(), C.cpu().numpy(), rtol=1e-5, atol=1e-5)
+            A4 = torch.eye(4, device=DEV).repeat([n, 1, 1])
+            A4[:, :3, :3] = C[:, :3, :3]
+            np.testing.assert_allclose(out['A4'].cpu().numpy(), A4.cpu().numpy(), rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(out['t4'].cpu().numpy(), torch.nn.functional.pad(C[:, :3, 3], [0, 1]).cpu().numpy(), rtol=1e-5, atol=1e-5)
+        if p == 0.0 and G is not None:
+            assert torch.equal(out['G_inv'], torch.eye(3, device=DEV).repeat(n, 1, 1))
+
+
+def test_augment_pipe_native_params_statistics(native):
+    """The pipe with native parameters is the same random transformation family: with p = 0 it is the identity (up to the
+    resampling filters' float rounding), and the launch counters show ONE parameter kernel per call."""
+    AU = importlib.import_module(f'{PKG}.training.augment')
+    pipe = AU.AugmentPipe(**AU.augpipe_specs['bgc']).to(DEV)
+    x = torch.rand([8, 4, 64, 64], device=DEV) * 2 - 1
+    for fixed in (True, False):
+        AU.fixed_margin = fixed
+        try:
+            pipe.p.copy_(torch.as_tensor(0.0))
+            before = native.launch_counts()['ada_params']
+            y = pipe(x)
+            assert native.launch_counts()['ada_params'] == before + 1
+            np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), atol=2e-3)
+            pipe.p.copy_(torch.as_tensor(1.0))
+            y = pipe(x)
+            assert y.shape == x.shape and bool(torch.isfinite(y).all()) and float((y - x).abs().mean()) > 1e-2
+        finally:
+            AU.fixed_margin = False

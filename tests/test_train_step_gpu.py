@@ -326,8 +326,12 @@ def test_recorded_phases_equal_the_eager_loop(ada):
                 t.run_iteration()
             torch.cuda.synchronize()
             if graphs:
-                assert t.graphs.captured >= 2 * 4 + 3 + 1 and t.graphs.replays >= 5 * (2 * 2 + 2)
-                assert 'global_Greg' not in t.graphs._graphs and 'global_Gmain' in t.graphs._graphs
+                # every phase with work was recorded and either verified (two replays from the saved state reproduce the eager
+                # execution) or rejected and left eager -- e.g. a library GEMM whose split-K zero fill escapes the capture
+                G = t.graphs
+                print('recorded', sorted(map(str, G._graphs)), 'rejected', G.rejected)
+                assert G.captured + len(G.rejected) == 2 * 4 + 3 + 1 and G.captured >= 4 and G.replays >= 4 * 4
+                assert 'global_Greg' not in G._graphs and 'global_Greg' not in G.rejected
             w = [p.detach().float().clone() for m in [t.mapping_network, *t.local_G_list, *t.local_D_list, t.pos_estimator, t.global_D]
                  for p in m.parameters()]
             ema = [p.detach().float().clone() for p in t.global_G_ema['local_G_list'][0].parameters()]
@@ -349,5 +353,41 @@ def test_recorded_phases_equal_the_eager_loop(ada):
         assert set(s0) == set(s2)
         for k in s0:
             assert float(s0[k][0]) == float(s2[k][0]), k              # same number of reported elements
+    finally:
+        AU.fixed_margin = AU.side_stream_margin = False
+
+
+@pytest.mark.parametrize('graphs', [False, True])
+def test_base_trainer_config2_shapes_on_gpu(graphs):
+    """BASELINE configs[1] through ``training.training_loop.Trainer``: one StyleGAN2 G/D pair at 256x256 RGBA, bf16 on the top
+    4 resolutions in channels-last layout, ADA bgc (small channel counts; the full-size run is ``bench.py --workload single``).
+    Every phase fires at iteration 0, weights move, everything stays finite; with ``graphs`` the phases are recorded."""
+    TL, AU = mod('training.training_loop'), mod('training.augment')
+    native = load_pkg().native
+    AU.fixed_margin, AU.side_stream_margin = True, False
+    try:
+        kw = TL.default_kwargs(num_gpus=1, batch_gpu=4, resolution=256, num_fp16_res=4, fp16_dtype=torch.bfloat16)
+        kw.G_kwargs.synthesis_kwargs.update(channel_base=2048, channel_max=32, fp16_channels_last=True)
+        kw.D_kwargs.update(channel_base=2048, channel_max=32)
+        kw.D_kwargs.block_kwargs.fp16_channels_last = True
+        kw.augment_kwargs = dict(class_name='training.augment.AugmentPipe', **AU.augpipe_specs['bgc'])
+        kw.augment_p = 0.3
+        g = torch.Generator(device='cpu').manual_seed(0)
+        reals = [(torch.randint(0, 256, [4, 4, 256, 256], generator=g, dtype=torch.uint8).to(DEV), torch.zeros([4, 0], device=DEV))]
+        t = TL.Trainer(device=DEV, resident_batches=reals, random_seed=0, graphs=graphs, **kw)
+        assert [p.name for p in t.phases] == ['Gmain', 'Greg', 'Dmain', 'Dreg'] and t.G.synthesis.block_resolutions[-1] == 256
+        w0 = [p.detach().clone() for p in list(t.G.parameters()) + list(t.D.parameters())]
+        before = native.launch_counts()
+        assert t.run_iteration() == 4
+        after = native.launch_counts()
+        assert after['upfirdn2d_nhwc'] > before['upfirdn2d_nhwc'] and after['ada_params'] > before['ada_params']
+        for _ in range(3):
+            assert t.run_iteration() == 2
+        torch.cuda.synchronize()
+        w1 = list(t.G.parameters()) + list(t.D.parameters())
+        assert all(torch.isfinite(p).all() for p in w1)
+        assert sum(int(not torch.equal(a, b.detach())) for a, b in zip(w0, w1)) >= len(w0) - 2
+        if graphs:
+            assert t.graphs.captured + len(t.graphs.rejected) >= 4 and t.graphs.replays >= 2 * 2, (t.graphs.captured, t.graphs.rejected)
     finally:
         AU.fixed_margin = AU.side_stream_margin = False

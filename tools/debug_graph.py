@@ -54,6 +54,85 @@ def compare(name, fn, outs, n_replays=2):
 
 def main():
     AU, NW, U = mod('training.augment'), mod('training.networks'), mod('torch_utils.ops.upfirdn2d')
+    LS, PE = mod('training.loss'), mod('training.phase_engine')
+    AU.fixed_margin = True
+    torch.manual_seed(0)
+    x = torch.rand([4, 4, 64, 64], device=DEV) * 2 - 1
+    which = sys.argv[1:] or ['d', 'dbench', 'dopt', 'loss', 'lossopt']
+
+    def make_d():
+        return NW.Discriminator(img_resolution=64, img_channels=4, channel_base=512, channel_max=16, num_fp16_res=2, conv_clamp=256,
+                                block_kwargs=dict(fp16_dtype=torch.bfloat16), epilogue_kwargs=dict(mbstd_group_size=2)).to(DEV).train()
+
+    def d_case(name, D, with_opt):
+        params = list(D.parameters())
+        od = [torch.empty_like(p) for p in params] + [torch.empty([4, 1], device=DEV)]
+        opt = torch.optim.Adam(params, lr=0.002, betas=(0.0, 0.99), eps=1e-8, fused=True, capturable=True) if with_opt else None
+        sync = PE.GradSync()
+        w0 = [p.detach().clone() for p in params]
+
+        def step():
+            with torch.no_grad():
+                for p, w in zip(params, w0):
+                    p.copy_(w)                                  # same starting weights every call
+            for p in params:
+                p.grad = None
+            D.requires_grad_(True)
+            logits = D(x)
+            torch.nn.functional.softplus(logits).mean().backward()
+            D.requires_grad_(False)
+            if opt is not None:
+                flat = sync.pack(params, 'k')
+                sync.unpack(params, flat, 'k')
+                opt.step()
+                for dst, p in zip(od, params):
+                    dst.copy_(p.detach())
+            else:
+                for dst, p in zip(od, params):
+                    dst.copy_(p.grad)
+            od[-1].copy_(logits.detach())
+        compare(name, step, od)
+
+    if 'd' in which:
+        d_case('D fwd+bwd', make_d(), False)
+    if 'dbench' in which:
+        torch.backends.cudnn.benchmark = True
+        d_case('D fwd+bwd, cudnn.benchmark=True', make_d(), False)
+        torch.backends.cudnn.benchmark = False
+    if 'dopt' in which:
+        d_case('D fwd+bwd + pack/unpack + fused capturable Adam', make_d(), True)
+    if 'loss' in which or 'lossopt' in which:
+        G = NW.Generator(z_dim=32, w_dim=32, img_resolution=64, img_channels=4, mapping_kwargs=dict(num_layers=2),
+                         synthesis_kwargs=dict(channel_base=512, channel_max=16, num_fp16_res=2, conv_clamp=256, fp16_dtype=torch.bfloat16)).to(DEV).train().requires_grad_(False)
+        D = make_d().requires_grad_(False)
+        for ada in (False, True):
+            pipe = None
+            if ada:
+                pipe = AU.AugmentPipe(**AU.augpipe_specs['bgc']).to(DEV).requires_grad_(False)
+                pipe.p.copy_(torch.as_tensor(0.5))
+            loss = LS.StyleGAN2Loss(device=DEV, G_mapping=G.mapping, G_synthesis=G.synthesis, D=D, augment_pipe=pipe)
+            z = torch.randn([4, 32], device=DEV)
+            c0 = torch.zeros([4, 0], device=DEV)
+            for phase in ('Dmain', 'Gmain', 'Dreg', 'Greg'):
+                m = D if phase[0] == 'D' else G
+                params = list(m.parameters())
+                od = [torch.zeros_like(p) for p in params]
+
+                def step(phase=phase, m=m, params=params, od=od):
+                    for p in params:
+                        p.grad = None
+                    m.requires_grad_(True)
+                    loss.accumulate_gradients(phase=phase, real_img=x, gen_z=z, sync=True, gain=1, real_c=c0, gen_c=c0)
+                    m.requires_grad_(False)
+                    for dst, p in zip(od, params):
+                        if p.grad is not None:
+                            dst.copy_(p.grad)
+                compare(f'StyleGAN2Loss {phase} ada={ada}', step, od)
+
+
+def _old_main():
+
+    AU, NW, U = mod('training.augment'), mod('training.networks'), mod('torch_utils.ops.upfirdn2d')
     AU.fixed_margin = True
     torch.manual_seed(0)
     x = torch.rand([4, 4, 64, 64], device=DEV) * 2 - 1
