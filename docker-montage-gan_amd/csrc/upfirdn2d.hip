@@ -778,80 +778,6 @@ bool try_nhwc(const UfParams& p, hipStream_t s)
     return false;
 }
 
-// ---------------------------------------------------------------------------
-// Separable filter, both axes in ONE launch: y = upfirdn2d(upfirdn2d(x, f[None,:], x-axis), f[:,None], y-axis)
-// (reference upfirdn2d.py:253-257 runs the two passes as two launches with the [N,C,H,W'] intermediate in HBM).
-// ADA's geometric stage resamples every augmented batch with the 12-tap sym6 this way, four times per call.
-// One workgroup = one 16x64 output tile of one plane: input footprint -> LDS, row pass -> LDS (rounded to T and
-// scaled exactly as the first launch would have stored it), column pass -> HBM.  Runtime taps (<= 12) and
-// up/down factors; the receptive field is the integer index path of mg_axis(), evaluated on the tile.
-constexpr int SP_TW = 64, SP_TH = 16, SP_MAXF = 12;
-constexpr int SP_MAX_ROWS = (SP_TH - 1) * 2 + SP_MAXF + 1, SP_MAX_COLS = (SP_TW - 1) * 2 + SP_MAXF + 1;
-
-struct SepParams {
-    const void* x; const float* f; void* y;
-    int upx, upy, downx, downy, padx0, pady0, flip, fsize; float gain_pass;      // gain_pass = sqrt(total gain), applied per pass
-    int planes, in_h, in_w, out_h, out_w, tiles_x, tiles_y;
-};
-
-template <class T>
-__global__ void __launch_bounds__(256) upfirdn2d_sep_kernel(SepParams p)
-{
-    __shared__ float s_in[SP_MAX_ROWS * SP_MAX_COLS];
-    __shared__ float s_mid[SP_MAX_ROWS * SP_TW];
-    __shared__ float s_f[SP_MAXF];
-    const int tile_x = blockIdx.x % p.tiles_x, tile_y = (blockIdx.x / p.tiles_x) % p.tiles_y;
-    const int plane = blockIdx.x / (p.tiles_x * p.tiles_y);
-    const int ox0 = tile_x * SP_TW, oy0 = tile_y * SP_TH;
-    const int tw = min(SP_TW, p.out_w - ox0), th = min(SP_TH, p.out_h - oy0);
-    const int fs = p.fsize;
-    // unclamped input ranges the tile touches (zeros outside the image add nothing, in the same tap order)
-    const int ix_lo = mg_floor_div(ox0 * p.downx + p.upx - 1 - p.padx0, p.upx);
-    const int ix_hi = mg_floor_div((ox0 + tw - 1) * p.downx + p.upx - 1 - p.padx0 + fs, p.upx);       // exclusive
-    const int iy_lo = mg_floor_div(oy0 * p.downy + p.upy - 1 - p.pady0, p.upy);
-    const int iy_hi = mg_floor_div((oy0 + th - 1) * p.downy + p.upy - 1 - p.pady0 + fs, p.upy);
-    const int cols = ix_hi - ix_lo, rows = iy_hi - iy_lo;
-
-    if (threadIdx.x < fs) s_f[threadIdx.x] = p.f[threadIdx.x];
-    const T* xp = (const T*)p.x + (size_t)plane * p.in_h * p.in_w;
-    for (int i = threadIdx.x; i < rows * cols; i += 256) {
-        const int r = i / cols, c = i - r * cols, iy = iy_lo + r, ix = ix_lo + c;
-        float v = 0.f;
-        if (ix >= 0 && iy >= 0 && ix < p.in_w && iy < p.in_h) v = (float)to_acc<T>(xp[(size_t)iy * p.in_w + ix]);
-        s_in[r * cols + c] = v;
-    }
-    __syncthreads();
-    const int fstep_x = p.flip ? p.upx : -p.upx, fstep_y = p.flip ? p.upy : -p.upy;
-    // row pass: [rows, cols] -> [rows, tw]
-    for (int i = threadIdx.x; i < rows * tw; i += 256) {
-        const int r = i / tw, ox = i - r * tw;
-        const int mid = (ox0 + ox) * p.downx + p.upx - 1 - p.padx0;
-        const int i0 = mg_floor_div(mid, p.upx), count = mg_floor_div(mid + fs, p.upx) - i0;
-        int ff = mid + fs - (i0 + 1) * p.upx;
-        if (p.flip) ff = fs - 1 - ff;
-        const float* src = s_in + r * cols + (i0 - ix_lo);
-        float v = 0.f;
-        for (int j = 0; j < count; j++) v = __builtin_fmaf(src[j], s_f[ff + j * fstep_x], v);
-        v *= p.gain_pass;
-        s_mid[r * SP_TW + ox] = (float)to_acc<T>(from_acc<T>(v));          // what the first launch would have stored
-    }
-    __syncthreads();
-    // column pass: [rows, tw] -> [th, tw]
-    T* yp = (T*)p.y + (size_t)plane * p.out_h * p.out_w;
-    for (int i = threadIdx.x; i < th * tw; i += 256) {
-        const int oy = i / tw, ox = i - oy * tw;
-        const int mid = (oy0 + oy) * p.downy + p.upy - 1 - p.pady0;
-        const int i0 = mg_floor_div(mid, p.upy), count = mg_floor_div(mid + fs, p.upy) - i0;
-        int ff = mid + fs - (i0 + 1) * p.upy;
-        if (p.flip) ff = fs - 1 - ff;
-        const float* src = s_mid + (i0 - iy_lo) * SP_TW + ox;
-        float v = 0.f;
-        for (int j = 0; j < count; j++) v = __builtin_fmaf(src[j * SP_TW], s_f[ff + j * fstep_y], v);
-        v *= p.gain_pass;
-        yp[(size_t)(oy0 + oy) * p.out_w + ox0 + ox] = from_acc<T>(v);
-    }
-}
-
 static thread_local bool g_last_was_stream = false;
 static thread_local bool g_last_was_nhwc = false;
 
@@ -956,33 +882,4 @@ extern "C" int mg_upfirdn2d_index_table(int32_t* table, int out_size, int in_siz
     hipLaunchKernelGGL(upfirdn2d_index_table_kernel, dim3((out_size + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        table, out_size, in_size, up, down, pad0, filter_size, flip ? 1 : 0);
     return mg_check_launch(-1, "upfirdn2d_index_table");
-}
-
-extern "C" int mg_upfirdn2d_sep(const void* x, const float* f, void* y, int dtype, int32_t n, int32_t c, int32_t in_h, int32_t in_w,
-                                int32_t out_h, int32_t out_w, int32_t fsize, int upx, int upy, int downx, int downy,
-                                int padx0, int pady0, int flip, float gain_pass, void* stream)
-{
-    MG_REQUIRE(x && f && y, "x must reside on the device");
-    MG_REQUIRE(dtype == MG_F32 || dtype == MG_F16 || dtype == MG_BF16, "upfirdn2d_sep: unsupported dtype %d", dtype);
-    MG_REQUIRE(fsize >= 1 && fsize <= SP_MAXF, "upfirdn2d_sep: 1..%d taps", SP_MAXF);
-    MG_REQUIRE((upx == 1 || upx == 2) && (upy == 1 || upy == 2) && (downx == 1 || downx == 2) && (downy == 1 || downy == 2),
-               "upfirdn2d_sep: up and down must be 1 or 2");
-    MG_REQUIRE(n >= 0 && c >= 1 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, "output must be at least 1x1");
-    MG_REQUIRE((int64_t)n * c * in_h * in_w <= INT32_MAX && (int64_t)n * c * out_h * out_w <= INT32_MAX, "x is too large");
-    if (n == 0) return MG_OK;
-    SepParams p;
-    p.x = x; p.f = f; p.y = y; p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0;
-    p.flip = flip ? 1 : 0; p.fsize = fsize; p.gain_pass = gain_pass;
-    p.planes = n * c; p.in_h = in_h; p.in_w = in_w; p.out_h = out_h; p.out_w = out_w;
-    p.tiles_x = (out_w + SP_TW - 1) / SP_TW; p.tiles_y = (out_h + SP_TH - 1) / SP_TH;
-    int64_t blocks = (int64_t)p.tiles_x * p.tiles_y * p.planes;
-    MG_REQUIRE(blocks <= INT32_MAX, "x is too large");
-    hipStream_t s = (hipStream_t)stream;
-    int es = mg_dtype_size(dtype);
-    MgLaunchScope scope(MG_K_UPFIRDN2D_TILED, s, ((double)n * c * in_h * in_w + (double)n * c * out_h * out_w) * es);
-    MG_DISPATCH_DTYPE(dtype, {
-        if (sizeof(T) == 8) break;
-        hipLaunchKernelGGL((upfirdn2d_sep_kernel<T>), dim3((uint32_t)blocks), dim3(256), 0, s, p);
-    });
-    return mg_check_launch(MG_K_UPFIRDN2D_TILED, "upfirdn2d_sep");
 }

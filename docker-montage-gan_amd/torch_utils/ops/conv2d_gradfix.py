@@ -92,6 +92,16 @@ class _NoTime:
 _no_time = _NoTime()
 
 
+def _timed_call(input, weight_shape, n_products, kind):
+    """Measurement scope for a stride-1, padding-k//2 convolution computed outside this module's autograd classes (the fused
+    matrix-core kernel of ops/modconv3x3.py and the library gradients it calls): same accounting as ``timed`` below."""
+    if prof is None or not input.is_cuda:
+        return _no_time
+    oc, ic, kh, kw = weight_shape
+    tag = f'conv{kh}x{kw}s1 w{list(weight_shape)} x{list(input.shape)} nhwc {kind}'
+    return _Timed(2.0 * input.shape[0] * input.shape[2] * input.shape[3] * oc * ic * kh * kw * n_products, input.dtype, tag)
+
+
 def _pair(v):
     v = tuple(v) if isinstance(v, (tuple, list)) else (v, v)
     assert len(v) == 2 and all(isinstance(e, int) for e in v)

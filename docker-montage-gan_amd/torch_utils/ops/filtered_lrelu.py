@@ -7,10 +7,11 @@ SURVEY D1), so its definition here is the composition of the reference's own ops
     u = bias_act(t, act='lrelu', alpha=slope, gain=gain, clamp=clamp)
     y = upfirdn2d(u, fd, down=down, flip_filter=flip)
 
-``impl='cuda'`` keeps the up-sampled intermediate in LDS (csrc/fused.hip: filtered_lrelu_kernel);
-gradients come from the composition (``impl='ref'``), which on GPU tensors itself runs the native
-upfirdn2d / bias_act kernels.  Parity: against that composition ("parity unpinned" upstream, there
-is no reference implementation to pin it to).
+``impl='cuda'`` keeps the up-sampled intermediate in LDS (csrc/fused.hip: filtered_lrelu_kernel).
+Status: a FORWARD-ONLY inference helper.  Nothing on the training step calls it (StyleGAN2's layers have no
+up-act-down sandwich), it is not part of the step-path kernel list or of the benchmark, and a tensor that requires grad takes the
+composition (``impl='ref'``), which on GPU tensors itself runs the native upfirdn2d / bias_act kernels.
+Parity: against that composition ("parity unpinned" upstream: there is no reference implementation to pin it to).
 """
 import numpy as np
 import torch

@@ -1,0 +1,197 @@
+"""The 64-channel, full-resolution modulated 3x3 convolution as one matrix-core kernel.
+
+``fused_modconv3x3(x, w, styles, dcoefs, noise, noise_strength, b, ...)`` computes what the training path of
+``modulated_conv2d`` plus the layer's ``bias_act`` computes (reference training/networks.py:37-98, 311-313)
+
+    y = clamp(act(conv3x3(x * styles[N,Ci,1,1], w) * dcoefs[N,Co,1,1] + noise * noise_strength + b) * gain)
+
+-- today three launches and six trips of the activation through HBM (modulation pass, library convolution, fused epilogue
+pass) -- in ONE launch of csrc/modconv.hip (``mg_modconv3x3_c64``: v_mfma_f32_32x32x16_bf16, weights resident in LDS,
+modulation applied while staging the halo tile, epilogue on the accumulators).  With ``styles = dcoefs = noise = None`` it is
+the discriminator's ``conv0`` + ``bias_act`` (reference :600-603).  Same roundings as the three-launch path (x*s to bf16, the
+convolution result to bf16, the fma sum to bf16), so the two agree to the order of the float32 accumulation.
+
+Scope: bf16, channels-last, 64 -> 64 channels, stride 1, padding 1, H % 8 == 0, W % 32 == 0 -- the 256x256 layers of the
+benchmark configuration, the largest activations of both networks.  Anything else keeps the three-launch path
+(``applicable()`` says which).
+
+Gradients.  A plain ``backward()`` is assembled from the kernels the three-launch path already uses, on the tensors the
+forward saved: the fused epilogue gradient (``mg_bwd_fused_nhwc``: d(conv out), d(dcoefs), d(bias), d(noise_strength) in one
+pass), the library's ``convolution_backward`` on the re-modulated input (one extra modulation pass instead of keeping x*s
+alive), and the fused modulation gradient.  Under ``create_graph=True`` (path-length regularisation) the backward re-runs the
+differentiable three-launch composition on the saved inputs, so gradients of any order exist.
+"""
+import os
+
+import torch
+
+from .. import native
+from . import bias_act as _ba
+from . import conv2d_gradfix
+from . import modconv_epilogue as _me
+
+# Module switch.  OFF by default: in isolation the kernel beats the three launches it replaces (forward 380 vs 624 us at
+# [32,64,256,256], profiles/r02_modconv_microbench.log) but over the whole training step the gain is inside the run-to-run noise
+# (690 vs 684 ms, profiles/r02_bench_b32_modconv_{on,off}.json): its phases -- stage, MFMA, epilogue -- run one after the other at
+# one workgroup per CU.  MG_MODCONV=1 turns it on; the parity tests exercise it either way.
+enabled = os.environ.get('MG_MODCONV', '0') == '1'
+
+
+def applicable(x, weight, up=1, down=1):
+    """True where the kernel's scope covers the call (GPU, bf16, channels-last, 64 -> 64, 3x3, no resampling, tile-aligned)."""
+    return (enabled and x.is_cuda and x.dtype == torch.bfloat16 and x.ndim == 4 and up == 1 and down == 1
+            and tuple(weight.shape) == (64, 64, 3, 3) and x.shape[1] == 64 and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0
+            and x.shape[0] > 0 and _me._is_nhwc(x))
+
+
+def _launch(x, w, s32, d32, nz32, nz_stride, strength32, b16, want_conv, want_xs, act_idx, alpha, gain, clamp):
+    n, c, h, wd = x.shape
+    y = torch.empty_like(x)
+    yconv = torch.empty_like(x) if want_conv else None
+    xs = torch.empty_like(x) if want_xs else None
+    with native.guard(x.device):
+        native.check(native.lib().mg_modconv3x3_c64(
+            native.ptr(x), native.ptr(w), native.ptr(s32), native.ptr(d32), native.ptr(nz32), native.ptr(strength32), native.ptr(b16),
+            native.ptr(yconv), native.ptr(y), native.ptr(xs), n, h, wd, nz_stride, act_idx, alpha, gain, clamp, native.stream_ptr(x.device)))
+    return y, yconv, xs
+
+
+def _composition(x, w, styles, dcoefs, noise, strength, b, act, alpha, gain, clamp):
+    """The differentiable three-launch path (what the layers run where the kernel does not apply)."""
+    xs = _me.channel_scale(x, styles) if styles is not None else x
+    yc = conv2d_gradfix.conv2d(xs, w, padding=1)
+    if dcoefs is None and noise is None:
+        return _ba.bias_act(yc, b.to(yc.dtype) if b is not None else None, act=act, alpha=alpha, gain=gain, clamp=None if clamp < 0 else clamp)
+    return _me.modconv_epilogue(yc, dcoefs, noise, b, act=act, alpha=alpha, gain=gain, clamp=None if clamp < 0 else clamp,
+                                noise_strength=strength)
+
+
+_cache = dict()
+
+
+def _fused(act, alpha, gain, clamp):
+    key = (act, alpha, gain, clamp)
+    if key in _cache:
+        return _cache[key]
+    spec = _ba.activation_funcs[act]
+    idx = spec.cuda_idx
+    assert idx in (1, 3), 'linear or lrelu'
+    null = _ba._null_tensor
+
+    class FusedModConv3x3(torch.autograd.Function):
+        """inputs: x, w (bf16, channels-last), styles, dcoefs, noise (raw), strength (0-dim), b"""
+
+        @staticmethod
+        def forward(ctx, x, w, styles, dcoefs, noise, strength, b):
+            n, c, h, wd = x.shape
+            s32 = styles.detach().to(torch.float32).contiguous() if styles is not None else None
+            d32 = dcoefs.detach().to(torch.float32).contiguous() if dcoefs is not None else None
+            nz32, nz_stride, st32 = None, 0, None
+            if noise is not None:
+                assert noise.numel() in (h * wd, n * h * wd), 'noise must be [H,W] or [N,1,H,W]'
+                nz32 = noise.detach().to(torch.float32).contiguous()
+                nz_stride = h * wd if noise.numel() == n * h * wd and n > 1 else 0
+                if strength is not None:
+                    st32 = strength.detach().to(torch.float32).reshape(1).contiguous()
+            b16 = b.detach().to(x.dtype).contiguous() if b is not None else None
+            wc = w.detach()
+            assert wc.is_contiguous(memory_format=torch.channels_last) and wc.dtype == x.dtype
+            need_bwd = any(ctx.needs_input_grad)
+            # the weight gradient of the convolution reads x * s: written by the same launch (one more store of the tile
+            # while it is in registers) rather than recomputed in the backward pass (a read and a write)
+            want_xs = need_bwd and styles is not None and ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled
+            want_conv = need_bwd and dcoefs is not None      # only the demodulation gradient reads the raw convolution output
+            with conv2d_gradfix._timed_call(x, (64, 64, 3, 3), 1, 'fwd [mg_modconv3x3_c64]'):
+                y, yconv, xs = _launch(x, wc, s32, d32, nz32, nz_stride, st32, b16, want_conv, want_xs, idx, alpha, gain, clamp)
+            if need_bwd:
+                ctx.save_for_backward(x, w, styles if styles is not None else null, dcoefs if dcoefs is not None else null,
+                                      yconv if yconv is not None else null, y, xs if xs is not None else null,
+                                      nz32 if nz32 is not None else null, st32 if st32 is not None else null,
+                                      noise if noise is not None else null, strength if strength is not None else null,
+                                      b if b is not None else null)
+            ctx.has = (styles is not None, dcoefs is not None, noise is not None, strength is not None, b is not None)
+            ctx.nz_stride = nz_stride
+            ctx.b_dtype = None if b is None else b.dtype
+            ctx.s_dtype = None if strength is None else strength.dtype
+            return y
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w, styles, dcoefs, yconv, y, xs_saved, nz32, st32, noise, strength, b = ctx.saved_tensors
+            has_s, has_d, has_nz, has_st, has_b = ctx.has
+            need = ctx.needs_input_grad          # x, w, styles, dcoefs, noise, strength, b
+            if torch.is_grad_enabled():
+                # create_graph=True: differentiate the three-launch composition of the saved inputs
+                ins = [x, w] + [t for t, h_ in ((styles, has_s), (dcoefs, has_d), (noise, has_nz), (strength, has_st), (b, has_b)) if h_]
+                live = [t for t in ins if t.requires_grad]
+                with torch.enable_grad():
+                    out = _composition(x, w, styles if has_s else None, dcoefs if has_d else None, noise if has_nz else None,
+                                       strength if has_st else None, b if has_b else None, act, alpha, gain, clamp)
+                    grads = torch.autograd.grad([out], live, [dy], create_graph=True, allow_unused=True)
+                table = {id(t): g for t, g in zip(live, grads)}
+                full = [x, w, styles if has_s else None, dcoefs if has_d else None, noise if has_nz else None,
+                        strength if has_st else None, b if has_b else None]
+                return tuple(table.get(id(t)) if (t is not None and nd) else None for t, nd in zip(full, need))
+            n, c, h, wd = x.shape
+            assert not (has_nz and need[4]), 'a noise tensor that wants its own gradient takes the three-launch path'
+            # (1) epilogue: d(conv out) and the float32 reductions, one pass
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            ident = (act == 'linear' and gain == 1 and clamp < 0)
+            want_gd, want_gb, want_gs = has_d and need[3], has_b and need[6], has_nz and has_st and need[5]
+            dyc = torch.empty_like(x)
+            acc = torch.zeros([2 * n * c + native.GS_SLOTS], dtype=torch.float32, device=x.device)
+            gd_a, gb_a, gs_a = acc[:n * c], acc[n * c:2 * n * c], acc[2 * n * c:]
+            d32 = dcoefs.to(torch.float32).contiguous() if has_d else None
+            with native.guard(x.device):
+                native.check(native.lib().mg_bwd_fused_nhwc(
+                    native.ptr(dy), native.ptr(None if ident else y), native.ptr(yconv if want_gd else None), native.ptr(d32),
+                    native.ptr(nz32 if want_gs else None), native.ptr(dyc), native.ptr(gd_a if want_gd else None),
+                    native.ptr(gb_a if want_gb else None), native.ptr(gs_a if want_gs else None), native.dtype_code(x.dtype), idx, alpha, gain,
+                    clamp, ctx.nz_stride, n, c, h * wd, native.stream_ptr(x.device)))
+            gd = gd_a.reshape(n, c).to(dcoefs.dtype) if want_gd else None
+            gb = gb_a.reshape(n, c).sum(0).to(ctx.b_dtype) if want_gb else None
+            gs = gs_a.sum().to(ctx.s_dtype) if want_gs else None
+            # (2) convolution: the library's gradients, on the re-modulated input
+            need_w = bool(need[1] and not conv2d_gradfix.weight_gradients_disabled)
+            need_xs = need[0] or (has_s and need[2])
+            dx = dw = ds = None
+            if need_xs or need_w:
+                if has_s and need_w:
+                    xs = xs_saved if xs_saved.numel() else _me.channel_scale(x.detach(), styles.detach())
+                else:
+                    xs = x.detach()
+                with conv2d_gradfix._timed_call(xs, (64, 64, 3, 3), int(bool(need_xs)) + int(need_w), 'bwd' + str(int(bool(need_xs)) + int(need_w))):
+                    dxs, dw, _ = torch.ops.aten.convolution_backward(dyc, xs, w.detach(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                                     [bool(need_xs), need_w, False])
+                if not need_w:
+                    dw = None
+                # (3) modulation: dx = dxs * s, ds = sum_hw dxs * x, one pass
+                if need_xs and has_s:
+                    dx = torch.empty_like(x)
+                    gsd = torch.zeros([n * c], dtype=torch.float32, device=x.device) if need[2] else None
+                    s32 = styles.to(torch.float32).contiguous()
+                    with native.guard(x.device):
+                        native.check(native.lib().mg_bwd_fused_nhwc(
+                            native.ptr(dxs), native.ptr(None), native.ptr(x if need[2] else None), native.ptr(s32), native.ptr(None),
+                            native.ptr(dx), native.ptr(gsd), native.ptr(None), native.ptr(None), native.dtype_code(x.dtype), 1, 0.0, 1.0,
+                            -1.0, 0, n, c, h * wd, native.stream_ptr(x.device)))
+                    ds = gsd.reshape(n, c).to(styles.dtype) if need[2] else None
+                    if not need[0]:
+                        dx = None
+                elif need_xs:
+                    dx = dxs
+            return dx, dw, ds, gd, None, gs, gb
+
+    _cache[key] = FusedModConv3x3
+    return FusedModConv3x3
+
+
+def fused_modconv3x3(x, w, styles=None, dcoefs=None, noise=None, noise_strength=None, b=None, act='lrelu', alpha=None, gain=None,
+                     clamp=None):
+    """See the module docstring.  The caller checks ``applicable(x, w)`` first."""
+    spec = _ba.activation_funcs[act]
+    alpha = float(spec.def_alpha if alpha is None else alpha)
+    gain = float(spec.def_gain if gain is None else gain)
+    clamp = float(-1 if clamp is None else clamp)
+    _ba._init()
+    return _fused(act, alpha, gain, clamp).apply(x, w, styles, dcoefs, noise, noise_strength, b)

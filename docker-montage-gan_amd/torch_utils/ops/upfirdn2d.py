@@ -131,33 +131,6 @@ def _upfirdn2d_ref(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
     return x[:, :, ::downy, ::downx]
 
 
-# 1-D filters: both passes in ONE native launch (mg_upfirdn2d_sep, identical values) instead of two launches as upstream.
-# OFF by default: the first version of that kernel resolves the receptive field at run time and is VALU-bound on index
-# arithmetic -- measured 375 us per ADA resampling call against 2 x 108 us for the two compile-time-specialised tiled passes
-# (profiles/r01 notes in DESIGN.md).  Kept, tested for bit-identity, as the starting point for a specialised version.
-sep_one_launch = False
-
-
-def _separable_one_launch(x, f, upx, upy, downx, downy, px0, px1, py0, py1, flip, gain_pass):
-    """Both passes of a separable filter with the intermediate in LDS (mg_upfirdn2d_sep); None if the configuration
-    is outside what that kernel takes (the caller then runs the two launches)."""
-    if (x.dtype not in (torch.float32, torch.float16, torch.bfloat16) or not x.is_contiguous() or f.numel() > 12 or not f.is_contiguous()
-            or upx not in (1, 2) or upy not in (1, 2) or downx not in (1, 2) or downy not in (1, 2) or f.dtype != torch.float32):
-        return None
-    n, c, ih, iw = x.shape
-    fs = f.numel()
-    ow = (iw * upx + px0 + px1 - fs + downx) // downx
-    oh = (ih * upy + py0 + py1 - fs + downy) // downy
-    if ow < 1 or oh < 1 or iw * upx + px0 + px1 - fs + downx < 0 or ih * upy + py0 + py1 - fs + downy < 0:
-        return None
-    y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device)
-    if y.numel():
-        with native.guard(x.device):
-            native.check(native.lib().mg_upfirdn2d_sep(x.data_ptr(), f.data_ptr(), y.data_ptr(), native.dtype_code(x.dtype), n, c, ih, iw, oh, ow,
-                                                       fs, upx, upy, downx, downy, px0, py0, 1 if flip else 0, gain_pass, native.stream_ptr(x.device)))
-    return y
-
-
 _upfirdn2d_cuda_cache = dict()
 
 
@@ -191,10 +164,8 @@ def _upfirdn2d_cuda(up=1, down=1, padding=0, flip_filter=False, gain=1):
                 y = _plugin.upfirdn2d(x, f, upx, upy, downx, downy, px0, px1, py0, py1, flip_filter, gain)
             else:   # separable: a row pass then a column pass, sqrt(gain) each (:253-257)
                 g = float(np.sqrt(gain))
-                y = _separable_one_launch(x, f, upx, upy, downx, downy, px0, px1, py0, py1, flip_filter, g) if sep_one_launch else None
-                if y is None:
-                    y = _plugin.upfirdn2d(x, f.unsqueeze(0), upx, 1, downx, 1, px0, px1, 0, 0, flip_filter, g)
-                    y = _plugin.upfirdn2d(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, py0, py1, flip_filter, g)
+                y = _plugin.upfirdn2d(x, f.unsqueeze(0), upx, 1, downx, 1, px0, px1, 0, 0, flip_filter, g)
+                y = _plugin.upfirdn2d(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, py0, py1, flip_filter, g)
             ctx.save_for_backward(f)
             ctx.x_shape = x.shape
             return y

@@ -25,7 +25,7 @@ from ..torch_utils.ops import conv2d_resample
 from ..torch_utils.ops import demod
 from ..torch_utils.ops import fma
 from ..torch_utils.ops import modconv_epilogue
-from ..torch_utils.ops import small_linear
+from ..torch_utils.ops import modconv3x3
 from ..torch_utils.ops import upfirdn2d
 from . import weight_prep
 
@@ -124,8 +124,8 @@ class FullyConnectedLayer(torch.nn.Module):
                 if self.bias_gain != 1:
                     b = b * self.bias_gain
         if self.activation == 'linear' and b is not None:
-            return small_linear.small_linear(x, w, b)                   # torch.addmm(b.unsqueeze(0), x, w.t())
-        return bias_act.bias_act(small_linear.small_linear(x, w), b, act=self.activation)
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
 
 
 class Conv2dLayer(torch.nn.Module):
@@ -163,6 +163,11 @@ class Conv2dLayer(torch.nn.Module):
     def forward(self, x, gain=1):
         w = weight_prep.get(self.weight, self.weight_gain, x.dtype)           # (weight * weight_gain).to(x.dtype)
         b = weight_prep.get(self.bias, 1, x.dtype) if self.bias is not None else None        # bias.to(x.dtype)
+        if (self.activation in ('linear', 'lrelu') and modconv3x3.applicable(x, w, up=self.up, down=self.down)
+                and w.is_contiguous(memory_format=torch.channels_last)):
+            # 64 -> 64 channels at full resolution (the discriminator's first conv0): convolution + bias_act in ONE kernel
+            return modconv3x3.fused_modconv3x3(x, w, b=b, act=self.activation, gain=self.act_gain * gain,
+                                               clamp=self.conv_clamp * gain if self.conv_clamp is not None else None)
         x = conv2d_resample.conv2d_resample(x=x, w=w, f=self.resample_filter, up=self.up, down=self.down,
                                             padding=self.padding, flip_weight=(self.up == 1))
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
@@ -287,8 +292,12 @@ class SynthesisLayer(torch.nn.Module):
                 weight = weight * (1 / np.sqrt(np.prod(weight.shape[1:])) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
                 st = st / st.norm(float('inf'), dim=1, keepdim=True)
             dcoefs = _demod_coefs(weight, st)
-            y = modconv_epilogue.channel_scale(x, st)
             wc = weight_prep.get(weight, 1, x.dtype) if weight is self.weight else weight.to(x.dtype)
+            if modconv3x3.applicable(x, wc, up=self.up) and wc.is_contiguous(memory_format=torch.channels_last):
+                # the 64-channel full-resolution layer: modulation, convolution and epilogue in ONE matrix-core kernel
+                return modconv3x3.fused_modconv3x3(x, wc, st, dcoefs, noise_raw, self.noise_strength if noise_raw is not None else None,
+                                                   self.bias, act=self.activation, gain=act_gain, clamp=act_clamp)
+            y = modconv_epilogue.channel_scale(x, st)
             y = conv2d_resample.conv2d_resample(x=y, w=wc, f=self.resample_filter, up=self.up,
                                                 padding=self.padding, flip_weight=flip_weight)
             if y.is_contiguous() or modconv_epilogue._is_nhwc(y):

@@ -329,7 +329,7 @@ class PhaseGraphs:
 
     ``verify=True`` (default) proves every recording before it is trusted: the state the phase may modify
     (``state_fn()``) and the generator state are saved before the eager execution; after recording, the graph is replayed
-    TWICE from that same saved state and must land on the eager result both times (within the run-to-run spread float
+    ``verify_replays`` (3) times from that same saved state and must land on the eager result every time (within the run-to-run spread float
     atomics cause).  A library routine that prepares a buffer outside the captured stream -- seen on ROCm 7.2 with a
     split-K weight-gradient GEMM whose zero fill is not recorded: first replay right, second replay accumulates onto stale
     memory -- fails the second replay; that phase then simply stays eager (``rejected``).
@@ -343,9 +343,10 @@ class PhaseGraphs:
     ``share_pool=True`` lets the graphs reuse each other's scratch memory (they replay strictly one after another).
     """
 
-    def __init__(self, device, warmup=1, verify=True, verify_tol=0.02, verify_tol_loose=0.5, share_pool=False):
+    def __init__(self, device, warmup=1, verify=True, verify_tol=0.02, verify_tol_loose=0.5, share_pool=False, verify_replays=3):
         self.device = torch.device(device)
         self.warmup, self.verify, self.verify_tol, self.verify_tol_loose = warmup, verify, verify_tol, verify_tol_loose
+        self.verify_replays = verify_replays
         self._seen = dict()         # key -> eager executions so far
         self._graphs = dict()       # key -> torch.cuda.CUDAGraph
         self.rejected = dict()      # key -> reason (recorded, failed verification: stays eager)
@@ -431,7 +432,7 @@ class PhaseGraphs:
         g = self._capture(fn)
         if check:
             worst, why = 0.0, ''
-            for rep in range(2):
+            for rep in range(self.verify_replays):
                 torch._foreach_copy_(state, before)
                 torch.cuda.set_rng_state(rng_before, self.device)
                 g.replay()

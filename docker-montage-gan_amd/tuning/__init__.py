@@ -2,7 +2,9 @@
 
 `miopen/` holds MIOpen's *user find-db* and *user perf-db* text files written by one exhaustive search
 (`python bench.py --miopen-find --miopen-db-out DIR`, ~14 minutes on a fresh MI355X) over the convolution
-problems of the benchmark workload (batch 32/GPU, 256x256 RGBA, bf16 NHWC blocks + fp32 NCHW blocks).  They are
+problems of the benchmark workload (256x256 RGBA, bf16 NHWC blocks + fp32 NCHW blocks) at per-GPU batch 32 (BASELINE configs 2-4;
+140 problems, round 1) and, appended by a second search seeded with those files, at per-GPU batch 4 (BASELINE config 5: global batch
+32 over 8 GPUs; +138 problems, round 2: 470 -> 419 ms per eager step at batch 4).  Other batches miss the db and get MIOpen's heuristics.  They are
 measurements of MIOpen's own solvers on gfx950 -- which solver is fastest for which problem -- not code.
 
 `use_tuned_miopen_db()` points MIOpen at a private copy of those files (MIOPEN_USER_DB_PATH).  MIOpen's

@@ -70,9 +70,10 @@ enum {
     MG_K_AFFINE_WARP_BWD = 14,
     MG_K_CHANNEL_MIX = 15,
     MG_K_DEMOD = 16,
-    MG_K_LINEAR = 17,
+    /* 17: retired */
     MG_K_STATS = 18,
     MG_K_ADA_PARAMS = 19,
+    MG_K_MODCONV = 20,
     MG_K_COUNT = 24
 };
 
@@ -109,15 +110,6 @@ int mg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
  * coordinate o in [0, out_size) writes {in0, count, filter0} as computed on the
  * DEVICE by the same code the kernels use (upfirdn2d.cu:43-48, 60-65).
  * `table` is device memory, int32[out_size*3].                                */
-/* Separable filter on both axes in one launch: the two calls the reference's op makes for a 1-D filter
- * (upfirdn2d.py:253-257: f[None,:] along x, then f[:,None] along y, gain sqrt(gain) each) with the intermediate
- * kept in LDS.  x, y dense NCHW; f float32 [fsize <= 12]; up / down in {1,2} per axis; out sizes as for the two
- * calls; gain_pass = sqrt(gain).  Values are identical to the two-launch composition (same tap order, the
- * intermediate rounded to the tensor dtype).                                                               */
-int mg_upfirdn2d_sep(const void* x, const float* f, void* y, int dtype, int32_t n, int32_t c, int32_t in_h, int32_t in_w,
-                     int32_t out_h, int32_t out_w, int32_t fsize, int upx, int upy, int downx, int downy,
-                     int padx0, int pady0, int flip, float gain_pass, void* stream);
-
 int mg_upfirdn2d_index_table(int32_t* table, int out_size, int in_size,
                              int up, int down, int pad0, int filter_size,
                              int flip, void* stream);
@@ -189,14 +181,6 @@ int mg_demod_fwd(const float* w, const float* s, float* d, float* wsq, int32_t n
 int mg_demod_bwd(const float* w, const float* s, const float* d, const float* wsq, const float* g, float* ds, float* dw,
                  int32_t n, int32_t oc, int32_t ic, int32_t kk, int32_t channels_last, void* stream);
 
-/* ---- small-batch fully connected layer --------------------------------------------
- * y[M,O] = x[M,I] @ w[O,I]^T (+ b[O]), float32, M <= 64: FullyConnectedLayer (training/networks.py:104-133:
- * torch.addmm / matmul on the mapping network, the style affines, the discriminator heads).
- * mg_linear_bwd: gx[M,I] = g @ w, gw[O,I] = g^T @ x, gb[O] = sum_m g (each output may be NULL).               */
-int mg_linear_fwd(const float* x, const float* w, const float* b, float* y, int32_t m, int32_t ic, int32_t oc, void* stream);
-int mg_linear_bwd(const float* g, const float* x, const float* w, float* gx, float* gw, float* gb,
-                  int32_t m, int32_t ic, int32_t oc, void* stream);
-
 /* ---- ADA: affine resampling and colour matrix ------------------------------------
  * mg_affine_warp_fwd:  y = grid_sample(x, affine_grid(theta, [N,C,out_h,out_w], align_corners=False),
  *                          mode='bilinear', padding_mode='zeros', align_corners=False)
@@ -231,6 +215,23 @@ int mg_stats_accumulate(const void* x, int dtype, int64_t n, double* counter, vo
  */
 int mg_ada_params(const float* U, const float* Z, const float* p, int32_t n, int32_t nu, int32_t nz, const float* cfg, int32_t ncfg,
                   float* Ginv, float* margin, float* theta, float* Cmat, float* A4, float* t4, void* stream);
+
+/*
+ * mg_modconv3x3_c64: y = clamp(act(conv3x3(x * s[n,ci]) * d[n,co] + noise * strength + b[co]) * gain), 64 -> 64 channels, stride 1,
+ * padding 1, bf16 NHWC, on the matrix cores (v_mfma_f32_32x32x16_bf16) -- modulated_conv2d's training path plus the layer's
+ * bias_act in one launch (reference montage_gan/training/networks.py:37-98,311-313; with s = d = noise = NULL the
+ * discriminator's conv0 + bias_act, :600-603).  x, y, yconv [N,H,W,64] bf16; w [64][3][3][64] bf16 (channels_last of [O,I,3,3]);
+ * s, d [N,64] float32 (rounded to bf16 inside, as the reference's .to(x.dtype)); noise [N,H,W] or [H,W] float32 with
+ * noise_stride_n = H*W or 0, multiplied by the device scalar *strength; b [64] bf16.  yconv (the raw convolution output) and xs
+ * (the modulated input x * s, what the weight gradient of the convolution reads) are optional extra outputs for the backward pass;
+ * y is optional too.  H % 8 == 0, W % 32 == 0.  act = 1 (linear) or 3 (lrelu).
+ */
+int mg_modconv3x3_c64(const void* x, const void* w, const float* s, const float* d, const float* noise, const float* strength,
+                      const void* b, void* yconv, void* y, void* xs, int32_t n, int32_t h, int32_t wd, int64_t noise_stride_n,
+                      int act, float alpha, float gain, float clamp, void* stream);
+/* diagnostics: while `buf` (device memory, uint64[8]) is set, workgroup 0 of mg_modconv3x3_c64 leaves its cycle counts per phase
+ * (stage, prefetch issue, MFMA loop, epilogue, store) there; NULL switches it off (tools/bench_modconv.py). */
+void mg_modconv_debug_timing(void* buf);
 
 /* ---- alpha composite -------------------------------------------------------
  * x: [B, L, 4, H, W] contiguous (RGB + alpha, values nominally in [0,1]);

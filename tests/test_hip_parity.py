@@ -248,47 +248,6 @@ def test_channels_last_epilogue_and_backward_match_nchw(native, dtype):
         close_lowp(res[1][2].float().cpu().numpy(), res[0][2].float().cpu().numpy(), dtype, 'bias_act db')
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
-def test_upfirdn2d_separable_one_launch_equals_two_launches(native, oracle, dtype):
-    """1-D filters: the reference's op runs a row pass and a column pass (upfirdn2d.py:253-257).  mg_upfirdn2d_sep does
-    both in one launch with the intermediate in LDS; values and input gradients must be IDENTICAL to the two-launch
-    composition (same tap order, intermediate rounded to the tensor dtype), and the composition is pinned to the
-    oracle here once more.  Covers ADA's four resampling passes (12-tap sym6, up 2 / down 2, negative padding,
-    flipped filter), odd sizes and tile boundaries."""
-    U = op('upfirdn2d')
-    rng = np.random.RandomState(12)
-    f12 = T(np.asarray([0.0154, 0.0035, -0.118, -0.0483, 0.4911, 0.7876, 0.3379, -0.0726, -0.0211, 0.0447, 0.0018, -0.0078], dtype=np.float32))
-    f5 = T(np.asarray([1, 4, 6, 4, 1], dtype=np.float32) / 16)
-    cases = [
-        (U.upsample2d, dict(f=f12, up=2), [3, 4, 37, 41]),
-        (U.downsample2d, dict(f=f12, down=2, padding=-6, flip_filter=True), [2, 4, 100, 90]),
-        (U.downsample2d, dict(f=f12, down=2), [2, 3, 33, 130]),
-        (U.filter2d, dict(f=f12, gain=2.0), [2, 2, 20, 70]),
-        (U.filter2d, dict(f=f5, flip_filter=True), [1, 5, 17, 65]),
-        (U.upsample2d, dict(f=f5, up=2, padding=[1, 0, 2, -1]), [2, 2, 16, 16]),
-        (U.upfirdn2d, dict(f=f12, up=[2, 1], down=[1, 2], padding=[3, 2, 5, 4]), [1, 3, 40, 24]),
-    ]
-    try:
-        for fn, kw, shape in cases:
-            x0 = T(rng.randn(*shape).astype(np.float32)).to(dtype).to(DEV)
-            kw = dict(kw, f=kw['f'].to(DEV))
-            res = []
-            for one in (True, False):
-                U.sep_one_launch = one
-                x = x0.clone().requires_grad_(True)
-                y = fn(x, **kw)
-                gy = torch.ones_like(y) * torch.linspace(-1, 1, y.shape[-1], device=DEV).to(dtype)
-                gx, = torch.autograd.grad([y], [x], [gy])
-                res.append((y.detach(), gx))
-            assert torch.equal(res[0][0], res[1][0]), (fn.__name__, shape, dtype)
-            assert torch.equal(res[0][1], res[1][1]), ('grad', fn.__name__, shape, dtype)
-            if fn is U.upsample2d and kw['f'].numel() == 12 and dtype == torch.float32:
-                want = oracle.upfirdn2d_api(x0.float().cpu().numpy(), np.outer(f12.numpy(), f12.numpy()), up=2, padding=[6, 5, 6, 5], gain=4)
-                np.testing.assert_allclose(res[0][0].float().cpu().numpy(), want, rtol=1e-4, atol=1e-5)
-    finally:
-        U.sep_one_launch = True
-
-
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16, torch.float64])
 def test_upfirdn2d_dtypes_vs_oracle(native, oracle, dtype):
     rng = np.random.RandomState(11)
@@ -770,41 +729,6 @@ def test_demod_coefs_native_vs_oracle(native, oracle):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(b.abs().max()))
 
 
-def test_small_linear_native_vs_float64(native):
-    """csrc/linear.hip (FullyConnectedLayer on <= 64 rows): values and all three gradients against a float64 product,
-    ragged sizes (scalar tail path), no bias, and the double backward against the reference expression."""
-    L = op('small_linear')
-    L.enabled = True            # off by default (slower than the BLAS library in its first form); exactness is what is pinned here
-    g = torch.Generator().manual_seed(13)
-    k0 = native.launch_count(native.K_LINEAR)
-    for m, ic, oc, bias in [(32, 512, 512, True), (32, 512, 64, True), (4, 64, 512, False), (7, 100, 37, True), (1, 513, 5, True), (64, 2048, 8, False)]:
-        x = torch.randn([m, ic], generator=g).to(DEV).requires_grad_(True)
-        w = (torch.randn([oc, ic], generator=g) / np.sqrt(ic)).to(DEV).requires_grad_(True)
-        b = torch.randn([oc], generator=g).to(DEV).requires_grad_(True) if bias else None
-        y = L.small_linear(x, w, b)
-        gy = torch.randn([m, oc], generator=g).to(DEV)
-        grads = torch.autograd.grad([y], [x, w] + ([b] if bias else []), [gy])
-        x64, w64, g64 = x.detach().double().cpu(), w.detach().double().cpu(), gy.double().cpu()
-        want = x64 @ w64.t() + (b.detach().double().cpu() if bias else 0)
-        np.testing.assert_allclose(y.detach().cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(grads[0].cpu().numpy(), (g64 @ w64).numpy(), rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(grads[1].cpu().numpy(), (g64.t() @ x64).numpy(), rtol=1e-4, atol=1e-5)
-        if bias:
-            np.testing.assert_allclose(grads[2].cpu().numpy(), g64.sum(0).numpy(), rtol=1e-4, atol=1e-5)
-    assert native.launch_count(native.K_LINEAR) == k0 + 12
-    x = torch.randn([5, 24], generator=g).to(DEV).requires_grad_(True)
-    w = torch.randn([9, 24], generator=g).to(DEV).requires_grad_(True)
-    b = torch.randn([9], generator=g).to(DEV).requires_grad_(True)
-    res = []
-    for impl in ('cuda', 'ref'):
-        y = L.small_linear(x, w, b, impl=impl)
-        gx, = torch.autograd.grad([y.square().sum()], [x], create_graph=True)
-        res.append(torch.autograd.grad([gx.square().sum()], [x, w, b]))
-    L.enabled = False
-    for a, bb in zip(*res):
-        np.testing.assert_allclose(a.cpu().numpy(), bb.cpu().numpy(), rtol=1e-4, atol=1e-4)
-
-
 def test_profiling_hooks_report_kernel_time(native):
     B = op('bias_act')
     x = torch.randn([8, 64, 128, 128], device=DEV)
@@ -975,3 +899,121 @@ def test_augment_pipe_native_params_statistics(native):
             assert y.shape == x.shape and bool(torch.isfinite(y).all()) and float((y - x).abs().mean()) > 1e-2
         finally:
             AU.fixed_margin = False
+
+
+# --------------------------------------------------------------------------------------------
+# fused modulated 3x3 convolution on the matrix cores (csrc/modconv.hip)
+
+@pytest.fixture
+def modconv_on():
+    """The matrix-core kernel is opt-in (MG_MODCONV=1, see ops/modconv3x3.py): switched on for the duration of a test."""
+    M = op('modconv3x3')
+    old, M.enabled = M.enabled, True
+    yield M
+    M.enabled = old
+
+
+def _modconv_inputs(n, h, w, integer, seed, with_mod=True):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    cl = torch.channels_last
+    if integer:     # small integers: every product and partial sum is exact in bf16 / float32 -> bit-exact comparison
+        x = torch.randint(-2, 3, [n, 64, h, w], device=DEV, generator=g).to(torch.bfloat16)
+        wt = torch.randint(-1, 2, [64, 64, 3, 3], device=DEV, generator=g).to(torch.bfloat16)
+        s = torch.randint(1, 3, [n, 64], device=DEV, generator=g).float()
+        d = torch.ones([n, 64], device=DEV)
+        nz = torch.randint(-2, 3, [n, 1, h, w], device=DEV, generator=g).float()
+        st = torch.tensor(2.0, device=DEV)
+        b = torch.randint(-3, 4, [64], device=DEV, generator=g).float()
+    else:
+        x = torch.randn([n, 64, h, w], device=DEV, generator=g).to(torch.bfloat16)
+        wt = (torch.randn([64, 64, 3, 3], device=DEV, generator=g) / 24).to(torch.bfloat16)
+        s = torch.randn([n, 64], device=DEV, generator=g) * 0.5 + 1
+        d = torch.rand([n, 64], device=DEV, generator=g) + 0.5
+        nz = torch.randn([n, 1, h, w], device=DEV, generator=g)
+        st = torch.tensor(0.3, device=DEV)
+        b = torch.randn([64], device=DEV, generator=g) * 0.2
+    x, wt = x.contiguous(memory_format=cl), wt.contiguous(memory_format=cl)
+    if not with_mod:
+        s = d = nz = st = None
+    return x, wt, s, d, nz, st, b
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 32), (3, 16, 64), (2, 64, 32), (1, 256, 256)])
+@pytest.mark.parametrize('with_mod', [True, False])
+def test_fused_modconv3x3_integer_data_is_bit_exact(native, modconv_on, shape, with_mod):
+    """mg_modconv3x3_c64 on integer-valued data (exact in bf16 and float32) against the three-launch path: tile seams, image
+    borders, the MFMA operand / accumulator lane maps and the channels-last weight layout all show up as bit differences."""
+    M = op('modconv3x3')
+    n, h, w = shape
+    x, wt, s, d, nz, st, b = _modconv_inputs(n, h, w, True, 3, with_mod)
+    bb = b if with_mod else b.to(torch.bfloat16)
+    before = native.launch_counts()['modconv']
+    assert M.applicable(x, wt)
+    for act, gain, clamp in (('lrelu', 1.0, None), ('linear', 1.0, None), ('lrelu', 2.0, 16.0)):
+        y = M.fused_modconv3x3(x, wt, s, d, nz, st, bb, act=act, gain=gain, clamp=clamp)
+        ref = M._composition(x, wt, s, d, nz, st, bb, act, 0.2 if act == 'lrelu' else 0.0, gain, -1.0 if clamp is None else clamp)
+        assert y.is_contiguous(memory_format=torch.channels_last) and y.dtype == torch.bfloat16
+        assert torch.equal(y, ref), (act, float((y.float() - ref.float()).abs().max()))
+    assert native.launch_counts()['modconv'] == before + 3
+
+
+@pytest.mark.parametrize('with_mod', [True, False])
+def test_fused_modconv3x3_values_and_gradients(native, modconv_on, with_mod):
+    """Random data: forward and every gradient (x, weight, styles, dcoefs, noise strength, bias) against the three-launch path,
+    both with a plain backward and under create_graph=True (second-order term of the path-length regulariser)."""
+    M = op('modconv3x3')
+    n, h, w = 3, 32, 64
+    x, wt, s, d, nz, st, b = _modconv_inputs(n, h, w, False, 11, with_mod)
+    bb = b if with_mod else b.to(torch.bfloat16)
+    names = ['x', 'w'] + (['s', 'd', 'st', 'b'] if with_mod else ['b'])
+    dy = torch.randn([n, 64, h, w], device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def run(fused, second):
+        leaves = [t.clone().requires_grad_(True) for t in ([x, wt] + ([s, d, st, bb] if with_mod else [bb]))]
+        xx, ww = leaves[0], leaves[1]
+        ss, dd, stt, b_ = (leaves[2], leaves[3], leaves[4], leaves[5]) if with_mod else (None, None, None, leaves[2])
+        if fused:
+            y = M.fused_modconv3x3(xx, ww, ss, dd, nz, stt, b_, act='lrelu', gain=np.sqrt(2), clamp=256)
+        else:
+            y = M._composition(xx, ww, ss, dd, nz, stt, b_, 'lrelu', 0.2, float(np.sqrt(2)), 256.0)
+        if not second:
+            grads = torch.autograd.grad([y], leaves, [dy])
+            return [y.detach()] + list(grads)
+        g1 = torch.autograd.grad([y], [xx] + ([ss] if with_mod else []), [dy], create_graph=True)
+        tot = sum(t.float().square().sum() for t in g1)
+        g2 = torch.autograd.grad([tot], [ww] + ([ss] if with_mod else []), allow_unused=True)
+        return [t.detach() for t in g1] + [t for t in g2 if t is not None]
+    for second in (False, True):
+        got, want = run(True, second), run(False, second)
+        assert len(got) == len(want)
+        for i, (a, r) in enumerate(zip(got, want)):
+            scale = float(r.float().abs().max()) + 1e-6
+            err = float((a.float() - r.float()).abs().max())
+            assert err <= 3e-2 * scale, (second, i, names[i - 1] if (not second and i) else i, err, scale)
+            assert float((a.float() - r.float()).abs().mean()) <= 4e-3 * scale
+
+
+def test_synthesis_and_discriminator_take_the_fused_kernel(native, modconv_on):
+    """The 256x256 layers of the benchmark configuration (64 channels, bf16, channels-last) run mg_modconv3x3_c64 inside
+    SynthesisNetwork and Discriminator; outputs agree with the three-launch path."""
+    NW, M = importlib.import_module(f'{PKG}.training.networks'), op('modconv3x3')
+    torch.manual_seed(0)
+    S = NW.SynthesisNetwork(w_dim=64, img_resolution=256, img_channels=4, init_res=[8, 8], conv_config_index=3, channel_base=16384,
+                            channel_max=64, num_fp16_res=4, conv_clamp=256, fp16_dtype=torch.bfloat16, fp16_channels_last=True).to(DEV).train()
+    D = NW.Discriminator(img_resolution=256, img_channels=4, init_res=[8, 8], conv_config_index=3, channel_base=16384, channel_max=64,
+                         num_fp16_res=4, conv_clamp=256, block_kwargs=dict(fp16_dtype=torch.bfloat16, fp16_channels_last=True)).to(DEV).train()
+    ws = torch.randn([2, S.num_ws, 64], device=DEV)
+    res = []
+    for on in (True, False):
+        M.enabled = on
+        try:
+            before = native.launch_counts()['modconv']
+            img = S(ws, noise_mode='const')
+            logits = D(img)
+            used = native.launch_counts()['modconv'] - before
+            res.append((img.detach(), logits.detach(), used))
+        finally:
+            M.enabled = True        # (the fixture restores the default afterwards)
+    assert res[0][2] >= 2 and res[1][2] == 0            # at least G b256.conv1 and D b256.conv0 (here every 64-channel block qualifies)
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 3e-2 * float(res[1][0].abs().max())
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 3e-2 * float(res[1][1].abs().max()) + 1e-3

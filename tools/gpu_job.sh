@@ -1,8 +1,11 @@
 #!/bin/bash
-set -o pipefail
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 O=gpurun_out
-timeout -k 10 900 python -m pytest tests/test_aio_golden.py tests/test_train_step_gpu.py -q -m gpu -k "global_phase or stn or base_trainer or recorded" > $O/r2_gpu_tests2.log 2>&1
-echo "pytest rc=$?"; tail -12 $O/r2_gpu_tests2.log | cut -c1-300
-timeout -k 10 500 python bench.py --steps 16 --warmup 3 --no-cpu-baseline --conv-table $O/r2_conv_table_b32.csv > $O/r2_b32_default.json 2> $O/r2_b32_default.err
-echo "bench rc=$?"; cut -c1-300 $O/r2_b32_default.json; head -40 $O/r2_conv_table_b32.csv
+mkdir -p $O/miopen_b816 && cp docker-montage-gan_amd/tuning/miopen/*.txt $O/miopen_b816/
+( while true; do sleep 60; echo "[find] $(date +%T) $(wc -l $O/miopen_b816/*.ufdb.txt | tail -1)"; done ) &
+HB=$!
+timeout -k 10 560 python bench.py --batch-gpu 16 --graphs off --miopen find --miopen-db-out $O/miopen_b816 --steps 2 --warmup 1 --no-cpu-baseline --prof-steps 0 > $O/r2_find_b16.json 2> $O/r2_find_b16.err
+echo "find b16 rc=$?"
+timeout -k 10 560 python bench.py --batch-gpu 8 --graphs off --miopen find --miopen-db-out $O/miopen_b816 --steps 2 --warmup 1 --no-cpu-baseline --prof-steps 0 > $O/r2_find_b8.json 2> $O/r2_find_b8.err
+echo "find b8 rc=$?"; kill $HB
+wc -l $O/miopen_b816/*.txt

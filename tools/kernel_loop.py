@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch ONE native kernel configuration a few times (for rocprofv3 --pmc runs).
-usage: kernel_loop.py <upfirdn2d|up2|down2|bias_act|calib4|epilogue|bwd_fused> <dtype> [iters] [nchw|nhwc]"""
+usage: kernel_loop.py <upfirdn2d|up2|down2|bias_act|calib4|epilogue|bwd_fused|ada_up|ada_down|demod|modconv> <dtype> [iters] [nchw|nhwc]"""
 import importlib
 import os
 import sys
@@ -39,6 +39,29 @@ elif which == 'up2':
 elif which == 'down2':
     x = torch.randn([n, c, r, r], device=dev).to(dt).contiguous(memory_format=fmt)
     fn = lambda: U.upfirdn2d(x, f, down=2, padding=[1, 1, 1, 1])
+elif which in ('ada_up', 'ada_down'):
+    # the separable 12-tap sym6 passes of AugmentPipe's geometric stage on the padded RGBA batch (side-margin size: 256 + 2*96)
+    AU = importlib.import_module(f'{PKG}.training.augment')
+    f12 = U.setup_filter(AU.wavelets['sym6']).to(dev)
+    if which == 'ada_up':
+        x = torch.randn([n, 4, 448, 448], device=dev).to(dt)
+        fn = lambda: U.upsample2d(x, f12, up=2)
+    else:
+        x = torch.randn([n, 4, 2 * (r + 6), 2 * (r + 6)], device=dev).to(dt)
+        fn = lambda: U.downsample2d(x, f12, down=2, padding=-6, flip_filter=True)
+elif which == 'demod':
+    D = importlib.import_module(f'{PKG}.torch_utils.ops.demod')
+    w = torch.randn([512, 512, 3, 3], device=dev).contiguous(memory_format=fmt)
+    sst = torch.randn([n, 512], device=dev) + 1
+    x = w
+    fn = lambda: D.demod_coefs(w, sst)
+elif which == 'modconv':
+    M = importlib.import_module(f'{PKG}.torch_utils.ops.modconv3x3')
+    x = torch.randn([n, c, r, r], device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn([64, 64, 3, 3], device=dev) / 24).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    sst, dd = torch.randn([n, c], device=dev) + 1, torch.rand([n, c], device=dev) + 0.5
+    nz, st, b = torch.randn([n, 1, r, r], device=dev), torch.tensor(0.3, device=dev), torch.randn([c], device=dev)
+    fn = lambda: M.fused_modconv3x3(x, w, sst, dd, nz, st, b, act='lrelu', gain=1.4142, clamp=256)
 elif which == 'bwd_fused':
     x = torch.randn([n, c, r, r], device=dev).to(dt).contiguous(memory_format=fmt).requires_grad_(True)
     d = (torch.rand([n, c], device=dev) + 0.5).requires_grad_(True)
