@@ -40,9 +40,17 @@ __global__ void __launch_bounds__(256) affine_warp_fwd_kernel(const T* __restric
 {
     const uint32_t ohw = (uint32_t)ho * wo;
     const size_t ihw = (size_t)hi * wi;
-    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
-        const uint32_t n = idx / ohw, p = idx - n * ohw;
-        const int oy = p / wo, ox = p - oy * wo;
+    // One wave = an 8x8 patch of output pixels, one workgroup = 16x16: under a rotation the 64 source points of a patch
+    // stay within ~12 rows x 12 columns of the input (a row-major run of 64 output pixels would cut across up to 64 input rows).
+    const uint32_t tiles_x = ((uint32_t)wo + 15u) >> 4, tiles_y = ((uint32_t)ho + 15u) >> 4, tiles = tiles_x * tiles_y;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t lx = ((wv & 1u) << 3) + (lane & 7u), ly = ((wv >> 1) << 3) + (lane >> 3);
+    for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const uint32_t n = t / tiles, tt = t - n * tiles;
+        const uint32_t ty = tt / tiles_x, tx = tt - ty * tiles_x;
+        const int oy = (int)(ty * 16u + ly), ox = (int)(tx * 16u + lx);
+        if (oy >= ho || ox >= wo) continue;
+        const uint32_t p = (uint32_t)oy * wo + ox;
         const PixMap m = make_pixmap(theta + 6 * n, wi, hi, wo, ho);
         const float sx = __builtin_fmaf(m.a, (float)ox, __builtin_fmaf(m.b, (float)oy, m.c));
         const float sy = __builtin_fmaf(m.d, (float)ox, __builtin_fmaf(m.e, (float)oy, m.f));
@@ -80,9 +88,16 @@ __global__ void __launch_bounds__(256) affine_warp_bwd_kernel(const T* __restric
 {
     const uint32_t ihw = (uint32_t)hi * wi;
     const size_t ohw = (size_t)ho * wo;
-    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
-        const uint32_t n = idx / ihw, p = idx - n * ihw;
-        const int iy = p / wi, ix = p - iy * wi;
+    // same 8x8-per-wave patches, here over the INPUT lattice (the pre-images of a patch's pixels overlap on the output lattice)
+    const uint32_t tiles_x = ((uint32_t)wi + 15u) >> 4, tiles_y = ((uint32_t)hi + 15u) >> 4, tiles = tiles_x * tiles_y;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t lx = ((wv & 1u) << 3) + (lane & 7u), ly = ((wv >> 1) << 3) + (lane >> 3);
+    for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const uint32_t n = t / tiles, tt = t - n * tiles;
+        const uint32_t ty = tt / tiles_x, tx = tt - ty * tiles_x;
+        const int iy = (int)(ty * 16u + ly), ix = (int)(tx * 16u + lx);
+        if (iy >= hi || ix >= wi) continue;
+        const uint32_t p = (uint32_t)iy * wi + ix;
         const PixMap m = make_pixmap(theta + 6 * n, wi, hi, wo, ho);
         float acc[CMAX];
         #pragma unroll
@@ -396,9 +411,8 @@ extern "C" int mg_affine_warp_fwd(const void* x, const float* theta, void* y, in
     MG_REQUIRE(n >= 0 && c >= 1 && c <= 4 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, "affine_warp: bad shape (1..4 channels)");
     MG_REQUIRE((int64_t)n * c * in_h * in_w <= INT32_MAX && (int64_t)n * c * out_h * out_w <= INT32_MAX, "x is too large");
     if (n == 0) return MG_OK;
-    const uint32_t total = (uint32_t)n * out_h * out_w;
-    uint32_t blocks = (total + 255u) / 256u;
-    if (blocks > 256u * 32u) blocks = 256u * 32u;
+    const uint32_t total = (uint32_t)n * (((uint32_t)out_w + 15u) >> 4) * (((uint32_t)out_h + 15u) >> 4);      // 16x16-pixel tiles
+    uint32_t blocks = total < 256u * 64u ? total : 256u * 64u;
     hipStream_t s = (hipStream_t)stream;
     int es = mg_dtype_size(dtype);
     MgLaunchScope scope(MG_K_AFFINE_WARP_FWD, s, ((double)n * c * in_h * in_w + (double)n * c * out_h * out_w) * es);
@@ -417,9 +431,8 @@ extern "C" int mg_affine_warp_bwd(const void* dy, const float* theta, void* dx, 
     MG_REQUIRE(n >= 0 && c >= 1 && c <= 4 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, "affine_warp: bad shape (1..4 channels)");
     MG_REQUIRE((int64_t)n * c * in_h * in_w <= INT32_MAX && (int64_t)n * c * out_h * out_w <= INT32_MAX, "x is too large");
     if (n == 0) return MG_OK;
-    const uint32_t total = (uint32_t)n * in_h * in_w;
-    uint32_t blocks = (total + 255u) / 256u;
-    if (blocks > 256u * 32u) blocks = 256u * 32u;
+    const uint32_t total = (uint32_t)n * (((uint32_t)in_w + 15u) >> 4) * (((uint32_t)in_h + 15u) >> 4);        // 16x16-pixel tiles
+    uint32_t blocks = total < 256u * 64u ? total : 256u * 64u;
     hipStream_t s = (hipStream_t)stream;
     int es = mg_dtype_size(dtype);
     MgLaunchScope scope(MG_K_AFFINE_WARP_BWD, s, ((double)n * c * in_h * in_w + (double)n * c * out_h * out_w) * es);

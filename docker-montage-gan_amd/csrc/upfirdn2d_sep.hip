@@ -1,0 +1,181 @@
+// upfirdn2d_sep.hip -- 12-tap separable FIR resampling by 2, BOTH axes in one pass over HBM.
+//
+// The geometric stage of the augmentation pipe (reference training/augment.py:315-333) is
+//     reflect-pad -> upsample2d(sym6, x2) -> affine resample -> downsample2d(sym6, /2)
+// and upfirdn2d.py:253-257 runs every 1-D filter as a row pass followed by a column pass: four launches and two
+// intermediate images of 70-150 MB per call, 36 calls per training step (forward and adjoint).  Here one workgroup
+// stages an input tile (with its 5/10-sample apron) in LDS, filters it along x into a second LDS tile and along y
+// straight out of that tile into the coalesced stores, so each image crosses HBM once in and once out.
+//
+//   up   (up = 2, down = 1):  y[o] = g * sum_{t<6}  f[(q+10) - 2t] * x[(o+1-pad0-q)/2 + t],  q = (o+1-pad0) & 1
+//   down (up = 1, down = 2):  y[o] = g * sum_{t<12} f[11 - t]      * x[2o - pad0 + t]
+// per axis (f mirrored when `flip`), x = 0 outside the image: the receptive-field arithmetic of upfirdn2d.cu:43-48,60-75
+// for fsize = 12 written per polyphase branch.  Taps are summed in ascending input order, sqrt(gain) is applied after
+// each axis -- the order and the rounding points of the two-pass form.  float32, dense NCHW planes.
+#include "mg_common.h"
+
+namespace {
+
+struct SepArgs {
+    const float* x; const float* f; float* y;
+    int ih, iw, oh, ow;
+    int cx, cy;             // up: input index of tap 0 of output 0;  down: -pad0
+    int flip;
+    float gx, gy;           // gain per axis
+};
+
+__device__ __forceinline__ float tap(const float* __restrict__ f, int k, int flip) { return f[flip ? 11 - k : k]; }
+
+// ---- up: 64 x 64 outputs per workgroup from a 38 x 38 input tile -----------------------------------------------------------
+// QX / QY: parity of (1 - pad0) per axis = the polyphase branch of the EVEN outputs; the odd outputs take the other branch and,
+// when Q = 1, start one input sample later.
+template <int QX, int QY>
+__global__ void __launch_bounds__(256) sep12_up2_kernel(SepArgs a)
+{
+    constexpr int TI = 38, PITCH = 40;
+    __shared__ float s_in[TI * PITCH];
+    __shared__ __attribute__((aligned(8))) float s_h[TI * 64];
+    const int tid = threadIdx.x;
+    const int ox0 = blockIdx.x * 64, oy0 = blockIdx.y * 64;
+    const int ix0 = (ox0 >> 1) + a.cx, iy0 = (oy0 >> 1) + a.cy;
+    const float* __restrict__ xp = a.x + (size_t)blockIdx.z * a.ih * a.iw;
+
+    float fxa[6], fxb[6], fya[6], fyb[6];       // uniform: scalar loads
+    #pragma unroll
+    for (int t = 0; t < 6; t++) {
+        fxa[t] = tap(a.f, QX + 10 - 2 * t, a.flip);  fxb[t] = tap(a.f, 11 - QX - 2 * t, a.flip);
+        fya[t] = tap(a.f, QY + 10 - 2 * t, a.flip);  fyb[t] = tap(a.f, 11 - QY - 2 * t, a.flip);
+    }
+
+    for (int e = tid; e < TI * TI; e += 256) {
+        const int r = e / TI, c = e - r * TI;
+        const int gy = iy0 + r, gx = ix0 + c;
+        float v = 0.f;
+        if ((unsigned)gy < (unsigned)a.ih && (unsigned)gx < (unsigned)a.iw) v = xp[(size_t)gy * a.iw + gx];
+        s_in[r * PITCH + c] = v;
+    }
+    __syncthreads();
+
+    // along x: item = (row r, output pair j)
+    for (int e = tid; e < TI * 32; e += 256) {
+        const int r = e >> 5, j = e & 31;
+        const float* p = s_in + r * PITCH + j;
+        float v[7];
+        #pragma unroll
+        for (int t = 0; t < 7; t++) v[t] = p[t];
+        float sa = 0.f, sb = 0.f;
+        #pragma unroll
+        for (int t = 0; t < 6; t++) { sa = __builtin_fmaf(v[t], fxa[t], sa); sb = __builtin_fmaf(v[t + QX], fxb[t], sb); }
+        *reinterpret_cast<float2*>(s_h + r * 64 + 2 * j) = make_float2(sa * a.gx, sb * a.gx);
+    }
+    __syncthreads();
+
+    // along y: lane = output column, wave = 8 output row pairs; 13 (+1) tile rows slide through registers
+    const int ox = tid & 63, jy0 = (tid >> 6) * 8;
+    float h[14];
+    #pragma unroll
+    for (int t = 0; t < 13 + QY; t++) h[t] = s_h[(jy0 + t) * 64 + ox];
+    const int gx = ox0 + ox;
+    if (gx >= a.ow) return;
+    float* __restrict__ yp = a.y + (size_t)blockIdx.z * a.oh * a.ow + gx;
+    #pragma unroll
+    for (int q = 0; q < 8; q++) {
+        float sa = 0.f, sb = 0.f;
+        #pragma unroll
+        for (int t = 0; t < 6; t++) { sa = __builtin_fmaf(h[q + t], fya[t], sa); sb = __builtin_fmaf(h[q + QY + t], fyb[t], sb); }
+        const int gy = oy0 + 2 * (jy0 + q);
+        if (gy < a.oh)     yp[(size_t)gy * a.ow] = sa * a.gy;
+        if (gy + 1 < a.oh) yp[(size_t)(gy + 1) * a.ow] = sb * a.gy;
+    }
+}
+
+// ---- down: 64 x TOH outputs per workgroup from a 138 x (2 TOH + 10) input tile -----------------------------------------------
+template <int TOH>
+__global__ void __launch_bounds__(256) sep12_down2_kernel(SepArgs a)
+{
+    constexpr int TIW = 138, TIH = 2 * TOH + 10, PITCH = 140, RPT = TOH / 4;      // RPT output rows per lane
+    __shared__ __attribute__((aligned(8))) float s_in[TIH * PITCH];
+    __shared__ float s_h[TIH * 64];
+    const int tid = threadIdx.x;
+    const int ox0 = blockIdx.x * 64, oy0 = blockIdx.y * TOH;
+    const int ix0 = 2 * ox0 + a.cx, iy0 = 2 * oy0 + a.cy;
+    const float* __restrict__ xp = a.x + (size_t)blockIdx.z * a.ih * a.iw;
+
+    float fx[12];
+    #pragma unroll
+    for (int t = 0; t < 12; t++) fx[t] = tap(a.f, 11 - t, a.flip);
+
+    #pragma unroll 8
+    for (int e = tid; e < TIH * TIW; e += 256) {
+        const int r = e / TIW, c = e - r * TIW;
+        const int gy = iy0 + r, gx = ix0 + c;
+        float v = 0.f;
+        if ((unsigned)gy < (unsigned)a.ih && (unsigned)gx < (unsigned)a.iw) v = xp[(size_t)gy * a.iw + gx];
+        s_in[r * PITCH + c] = v;
+    }
+    __syncthreads();
+
+    // along x: lane j of row r reads its 12 samples as six 8-byte LDS reads (consecutive lanes, consecutive 8-byte words)
+    for (int e = tid; e < TIH * 64; e += 256) {
+        const int r = e >> 6, j = e & 63;
+        const float2* p = reinterpret_cast<const float2*>(s_in + r * PITCH + 2 * j);
+        float s = 0.f;
+        #pragma unroll
+        for (int t = 0; t < 6; t++) {
+            const float2 v = p[t];
+            s = __builtin_fmaf(v.x, fx[2 * t], s);
+            s = __builtin_fmaf(v.y, fx[2 * t + 1], s);
+        }
+        s_h[r * 64 + j] = s * a.gx;
+    }
+    __syncthreads();
+
+    // along y (the same taps: one 1-D filter for both axes)
+    const int ox = tid & 63, ly0 = (tid >> 6) * RPT;
+    float h[2 * (RPT - 1) + 12];
+    #pragma unroll
+    for (int t = 0; t < 2 * (RPT - 1) + 12; t++) h[t] = s_h[(2 * ly0 + t) * 64 + ox];
+    const int gx = ox0 + ox;
+    if (gx >= a.ow) return;
+    float* __restrict__ yp = a.y + (size_t)blockIdx.z * a.oh * a.ow + gx;
+    #pragma unroll
+    for (int q = 0; q < RPT; q++) {
+        float s = 0.f;
+        #pragma unroll
+        for (int t = 0; t < 12; t++) s = __builtin_fmaf(h[2 * q + t], fx[t], s);
+        const int gy = oy0 + ly0 + q;
+        if (gy < a.oh) yp[(size_t)gy * a.ow] = s * a.gy;
+    }
+}
+
+} // namespace
+
+// x [planes, ih, iw] -> y [planes, oh, ow], float32 dense; f: 12 float32 taps on the device; factor 2 in both axes, `up` nonzero:
+// upsample (down = 1), else downsample (up = 1); pad*0 as mg_upfirdn2d (the caller sizes y); gain_axis is applied after each axis.
+extern "C" int mg_upfirdn2d_sep12(const float* x, const float* f, float* y, int64_t planes, int32_t ih, int32_t iw, int32_t oh, int32_t ow,
+                                  int32_t up, int32_t padx0, int32_t pady0, int32_t flip, float gain_axis, void* stream)
+{
+    MG_REQUIRE(x && f && y, "upfirdn2d_sep12: x, f and y must reside on the device");
+    MG_REQUIRE(planes >= 0 && planes <= 65535 && ih >= 1 && iw >= 1 && oh >= 1 && ow >= 1, "upfirdn2d_sep12: bad shape");
+    MG_REQUIRE((int64_t)ih * iw < (1ll << 31) && (int64_t)oh * ow < (1ll << 31), "upfirdn2d_sep12: plane too large");
+    if (planes == 0) return MG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    MgLaunchScope scope(MG_K_UPFIRDN2D_SEP, st, 4.0 * (double)planes * ((double)ih * iw + (double)oh * ow));
+    SepArgs a;
+    a.x = x; a.f = f; a.y = y; a.ih = ih; a.iw = iw; a.oh = oh; a.ow = ow; a.flip = flip ? 1 : 0; a.gx = gain_axis; a.gy = gain_axis;
+    if (up) {
+        const int mx = 1 - padx0, my = 1 - pady0, qx = mx & 1, qy = my & 1;
+        a.cx = (mx - qx) >> 1; a.cy = (my - qy) >> 1;
+        const dim3 grid((uint32_t)((ow + 63) / 64), (uint32_t)((oh + 63) / 64), (uint32_t)planes);
+        if      (!qx && !qy) hipLaunchKernelGGL((sep12_up2_kernel<0, 0>), grid, dim3(256), 0, st, a);
+        else if ( qx && !qy) hipLaunchKernelGGL((sep12_up2_kernel<1, 0>), grid, dim3(256), 0, st, a);
+        else if (!qx &&  qy) hipLaunchKernelGGL((sep12_up2_kernel<0, 1>), grid, dim3(256), 0, st, a);
+        else                 hipLaunchKernelGGL((sep12_up2_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    } else {
+        a.cx = -padx0; a.cy = -pady0;
+        constexpr int TOH = 16;
+        const dim3 grid((uint32_t)((ow + 63) / 64), (uint32_t)((oh + TOH - 1) / TOH), (uint32_t)planes);
+        hipLaunchKernelGGL((sep12_down2_kernel<TOH>), grid, dim3(256), 0, st, a);
+    }
+    return mg_check_launch(MG_K_UPFIRDN2D_SEP, "upfirdn2d_sep12");
+}

@@ -102,6 +102,16 @@ def _timed_call(input, weight_shape, n_products, kind):
     return _Timed(2.0 * input.shape[0] * input.shape[2] * input.shape[3] * oc * ic * kh * kw * n_products, input.dtype, tag)
 
 
+# Data gradient of the square (C -> C, C >= 128) stride-1 3x3 convolutions on 16-bit channels-last tensors as a forward
+# convolution of dy with the flipped, transposed weights (plain backward only).  Measured per problem in
+# profiles/r02_conv_backward_split.log: 204 / 167 / 165 us against 280 / 244 / 224 us at 128 / 256 / 512 channels, batch 32.
+data_gradient_as_forward = True
+
+
+def _lowp_nhwc(t):
+    return t.is_cuda and t.dtype in (torch.bfloat16, torch.float16) and t.dim() == 4 and t.stride(1) == 1 and t.shape[1] > 1
+
+
 def _pair(v):
     v = tuple(v) if isinstance(v, (tuple, list)) else (v, v)
     assert len(v) == 2 and all(isinstance(e, int) for e in v)
@@ -167,6 +177,9 @@ def _conv2d_gradfix_build(transpose, weight_shape, stride, padding, output_paddi
         return tuple(input_shape[i + 2] - (output_shape[i + 2] - 1) * stride[i] - (1 - 2 * padding[i])
                      - dilation[i] * (weight_shape[i + 2] - 1) for i in range(2))
 
+    square3x3s1 = (not transpose and stride == (1, 1) and dilation == (1, 1) and groups == 1 and weight_shape[2:] == (3, 3)
+                   and weight_shape[0] == weight_shape[1] >= 128 and max(padding) <= 2)
+
     class Conv2d(torch.autograd.Function):
         @staticmethod
         def forward(ctx, input, weight, bias):
@@ -183,18 +196,25 @@ def _conv2d_gradfix_build(transpose, weight_shape, stride, padding, output_paddi
             input, weight = ctx.saved_tensors
             grad_input = grad_weight = grad_bias = None
             if not torch.is_grad_enabled():
-                # plain backward: both gradients from ONE aten::convolution_backward call (the same MIOpen kernels as the
-                # two differentiable ops below, without two more python autograd nodes per convolution)
+                # plain backward: aten::convolution_backward directly (the same MIOpen kernels as the two differentiable ops
+                # below, without two more python autograd nodes per convolution) -- one call PER gradient: on every problem
+                # of the step the two single-gradient calls together take no longer than the call that asks for both, and
+                # up to 100 us less (profiles/r02_conv_backward_split.log)
+                need_x = bool(ctx.needs_input_grad[0])
                 need_w = bool(ctx.needs_input_grad[1] and not weight_gradients_disabled)
-                if ctx.needs_input_grad[0] or need_w:
-                    with timed(input, grad_output, int(bool(ctx.needs_input_grad[0])) + int(need_w)):
-                        grad_input, grad_weight, _ = torch.ops.aten.convolution_backward(
-                            grad_output, input, weight, None, list(stride), list(padding), list(dilation), transpose,
-                            list(output_padding), groups, [bool(ctx.needs_input_grad[0]), need_w, False])
-                    if not ctx.needs_input_grad[0]:
-                        grad_input = None
-                    if not need_w:
-                        grad_weight = None
+                if need_x or need_w:
+                    with timed(input, grad_output, int(need_x) + int(need_w)):
+                        bwd_args = (grad_output, input, weight, None, list(stride), list(padding), list(dilation), transpose,
+                                    list(output_padding), groups)
+                        if need_x and data_gradient_as_forward and square3x3s1 and _lowp_nhwc(grad_output):
+                            # dx = dy (*) flipped, transposed w: the SAME problem as the layer's forward, whose solver runs at
+                            # 0.8-1.05 PFLOP/s where the library's data-gradient solver reaches 0.5-0.7
+                            wt = weight.flip([2, 3]).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+                            grad_input = torch.convolution(grad_output, wt, None, [1, 1], [2 - padding[0], 2 - padding[1]], [1, 1], False, [0, 0], 1)
+                        elif need_x:
+                            grad_input = torch.ops.aten.convolution_backward(*bwd_args, [True, False, False])[0]
+                        if need_w:
+                            grad_weight = torch.ops.aten.convolution_backward(*bwd_args, [False, True, False])[1]
                 if ctx.needs_input_grad[2]:
                     grad_bias = grad_output.sum([0, 2, 3])
                 return grad_input, grad_weight, grad_bias

@@ -143,6 +143,34 @@ class _NoCtx:
         pass
 
 
+sep12_enabled = True        # the one-pass 12-tap x2 resampler (csrc/upfirdn2d_sep.hip); False: always two mg_upfirdn2d passes
+
+
+def _sep12_applicable(x, f, upx, upy, downx, downy):
+    """A 12-tap 1-D filter by a factor of 2 in both axes on dense float32 NCHW: the ADA geometric stage (augment.py:317,331) and
+    its adjoint.  Everything else takes the two-pass form."""
+    return (sep12_enabled and (upx, upy, downx, downy) in ((2, 2, 1, 1), (1, 1, 2, 2)) and f.numel() == 12 and f.dtype == torch.float32
+            and x.dtype == torch.float32 and x.is_cuda and f.is_cuda and x.is_contiguous() and 0 < x.shape[0] * x.shape[1] <= 65535
+            and x.shape[2] >= 1 and x.shape[3] >= 1)
+
+
+def _sep12(x, f, up, px0, px1, py0, py1, flip_filter, gain_axis):
+    from .. import native
+    n, c, ih, iw = x.shape
+    if up:
+        oh, ow = ih * 2 + py0 + py1 - 11, iw * 2 + px0 + px1 - 11
+    else:
+        oh, ow = (ih + py0 + py1 - 10) // 2, (iw + px0 + px1 - 10) // 2
+    if oh < 1 or ow < 1:    # same message as the plugin (upfirdn2d.cpp:34)
+        raise RuntimeError('output must be at least 1x1')
+    y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device)
+    f = f.contiguous()
+    with native.guard(x.device):
+        native.check(native.lib().mg_upfirdn2d_sep12(native.ptr(x), native.ptr(f), native.ptr(y), n * c, ih, iw, oh, ow, int(up), px0, py0,
+                                                     int(flip_filter), gain_axis, native.stream_ptr(x.device)))
+    return y
+
+
 def _upfirdn2d_cuda(up=1, down=1, padding=0, flip_filter=False, gain=1):
     """autograd.Function class for one scalar configuration (cached, reference :226-285)."""
     upx, upy = _parse_scaling(up)
@@ -162,6 +190,8 @@ def _upfirdn2d_cuda(up=1, down=1, padding=0, flip_filter=False, gain=1):
             assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
             if f.ndim == 2:
                 y = _plugin.upfirdn2d(x, f, upx, upy, downx, downy, px0, px1, py0, py1, flip_filter, gain)
+            elif _sep12_applicable(x, f, upx, upy, downx, downy):
+                y = _sep12(x, f, upx == 2, px0, px1, py0, py1, flip_filter, float(np.sqrt(gain)))
             else:   # separable: a row pass then a column pass, sqrt(gain) each (:253-257)
                 g = float(np.sqrt(gain))
                 y = _plugin.upfirdn2d(x, f.unsqueeze(0), upx, 1, downx, 1, px0, px1, 0, 0, flip_filter, g)

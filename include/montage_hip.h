@@ -74,6 +74,7 @@ enum {
     MG_K_STATS = 18,
     MG_K_ADA_PARAMS = 19,
     MG_K_MODCONV = 20,
+    MG_K_UPFIRDN2D_SEP = 21,
     MG_K_COUNT = 24
 };
 
@@ -105,6 +106,14 @@ int mg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
                  const int32_t y_size[4], const int64_t y_stride[4],
                  int upx, int upy, int downx, int downy,
                  int padx0, int pady0, int flip, float gain, void* stream);
+
+/* The 1-D 12-tap filter by a factor of 2 along BOTH axes in one pass (upfirdn2d.py:253-257 runs such a filter as two
+ * mg_upfirdn2d calls): `up` != 0: up = 2, down = 1; else up = 1, down = 2.  x [planes, in_h, in_w] -> y [planes, out_h,
+ * out_w], float32, dense; f = 12 float32 taps on the device; pad*0 / flip as above; `gain_axis` multiplies after each
+ * axis (sqrt(gain) of the 2-D call).  planes <= 65535.                                                            */
+int mg_upfirdn2d_sep12(const float* x, const float* f, float* y, int64_t planes,
+                       int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                       int32_t up, int32_t padx0, int32_t pady0, int32_t flip, float gain_axis, void* stream);
 
 /* Integer index path only (the part that must be bit exact): for each output
  * coordinate o in [0, out_size) writes {in0, count, filter0} as computed on the

@@ -1,11 +1,16 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 O=gpurun_out
-mkdir -p $O/miopen_b816 && cp docker-montage-gan_amd/tuning/miopen/*.txt $O/miopen_b816/
-( while true; do sleep 60; echo "[find] $(date +%T) $(wc -l $O/miopen_b816/*.ufdb.txt | tail -1)"; done ) &
-HB=$!
-timeout -k 10 560 python bench.py --batch-gpu 16 --graphs off --miopen find --miopen-db-out $O/miopen_b816 --steps 2 --warmup 1 --no-cpu-baseline --prof-steps 0 > $O/r2_find_b16.json 2> $O/r2_find_b16.err
-echo "find b16 rc=$?"
-timeout -k 10 560 python bench.py --batch-gpu 8 --graphs off --miopen find --miopen-db-out $O/miopen_b816 --steps 2 --warmup 1 --no-cpu-baseline --prof-steps 0 > $O/r2_find_b8.json 2> $O/r2_find_b8.err
-echo "find b8 rc=$?"; kill $HB
-wc -l $O/miopen_b816/*.txt
+timeout -k 10 600 python -m pytest tests/test_hip_parity.py -x -q -m gpu > $O/r2_parity.log 2>&1
+rc=$?; echo "parity rc=$rc"; tail -3 $O/r2_parity.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 400 python bench.py --no-cpu-baseline > $O/r2_b32_split.json 2> $O/r2_b32_split.err
+echo "b32 rc=$?"; python -c "
+import json,sys
+d=json.loads(open('$O/r2_b32_split.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d.get('roofline_mfma'))"
+for b in 16 8 4; do
+timeout -k 10 300 python bench.py --batch-gpu $b --no-cpu-baseline --prof-steps 0 > $O/r2_b${b}_split.json 2> $O/r2_b${b}_split.err
+echo "b$b rc=$?"; python -c "
+import json,sys
+d=json.loads(open('$O/r2_b${b}_split.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['config'].get('phase_graphs'))"
+done
