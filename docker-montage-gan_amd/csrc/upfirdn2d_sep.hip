@@ -22,7 +22,12 @@ struct SepArgs {
     int cx, cy;             // up: input index of tap 0 of output 0;  down: -pad0
     int flip;
     float gx, gy;           // gain per axis
+    // up only: the input is a VIRTUAL reflect-padded image (torch.nn.functional.pad(mode='reflect')) of the sw x sh source at x:
+    // ih / iw are the padded sizes, (rx0, ry0) the left / top margins.  sw = 0: x is the input itself.
+    int sw, sh, rx0, ry0;
 };
+
+__device__ __forceinline__ int reflect(int t, int n) { return t < 0 ? -t : (t >= n ? 2 * (n - 1) - t : t); }
 
 __device__ __forceinline__ float tap(const float* __restrict__ f, int k, int flip) { return f[flip ? 11 - k : k]; }
 
@@ -38,7 +43,7 @@ __global__ void __launch_bounds__(256) sep12_up2_kernel(SepArgs a)
     const int tid = threadIdx.x;
     const int ox0 = blockIdx.x * 64, oy0 = blockIdx.y * 64;
     const int ix0 = (ox0 >> 1) + a.cx, iy0 = (oy0 >> 1) + a.cy;
-    const float* __restrict__ xp = a.x + (size_t)blockIdx.z * a.ih * a.iw;
+    const float* __restrict__ xp = a.x + (size_t)blockIdx.z * (a.sw ? (size_t)a.sh * a.sw : (size_t)a.ih * a.iw);
 
     float fxa[6], fxb[6], fya[6], fyb[6];       // uniform: scalar loads
     #pragma unroll
@@ -51,7 +56,8 @@ __global__ void __launch_bounds__(256) sep12_up2_kernel(SepArgs a)
         const int r = e / TI, c = e - r * TI;
         const int gy = iy0 + r, gx = ix0 + c;
         float v = 0.f;
-        if ((unsigned)gy < (unsigned)a.ih && (unsigned)gx < (unsigned)a.iw) v = xp[(size_t)gy * a.iw + gx];
+        if ((unsigned)gy < (unsigned)a.ih && (unsigned)gx < (unsigned)a.iw)
+            v = a.sw ? xp[(size_t)reflect(gy - a.ry0, a.sh) * a.sw + reflect(gx - a.rx0, a.sw)] : xp[(size_t)gy * a.iw + gx];
         s_in[r * PITCH + c] = v;
     }
     __syncthreads();
@@ -163,6 +169,7 @@ extern "C" int mg_upfirdn2d_sep12(const float* x, const float* f, float* y, int6
     MgLaunchScope scope(MG_K_UPFIRDN2D_SEP, st, 4.0 * (double)planes * ((double)ih * iw + (double)oh * ow));
     SepArgs a;
     a.x = x; a.f = f; a.y = y; a.ih = ih; a.iw = iw; a.oh = oh; a.ow = ow; a.flip = flip ? 1 : 0; a.gx = gain_axis; a.gy = gain_axis;
+    a.sw = a.sh = a.rx0 = a.ry0 = 0;
     if (up) {
         const int mx = 1 - padx0, my = 1 - pady0, qx = mx & 1, qy = my & 1;
         a.cx = (mx - qx) >> 1; a.cy = (my - qy) >> 1;
@@ -178,4 +185,28 @@ extern "C" int mg_upfirdn2d_sep12(const float* x, const float* f, float* y, int6
         hipLaunchKernelGGL((sep12_down2_kernel<TOH>), grid, dim3(256), 0, st, a);
     }
     return mg_check_launch(MG_K_UPFIRDN2D_SEP, "upfirdn2d_sep12");
+}
+
+// upsample2d(pad(x, [mx0, mx1, my0, my1], mode='reflect'), f12, up=2) of augment.py:315-317 without the padded image:
+// x [planes, sh, sw] -> y [planes, 2 (sh + my0 + my1), 2 (sw + mx0 + mx1)]; margins in [0, size - 1] (one reflection).
+extern "C" int mg_reflect_pad_upsample12(const float* x, const float* f, float* y, int64_t planes, int32_t sh, int32_t sw,
+                                         int32_t mx0, int32_t mx1, int32_t my0, int32_t my1, float gain_axis, void* stream)
+{
+    MG_REQUIRE(x && f && y, "reflect_pad_upsample12: x, f and y must reside on the device");
+    MG_REQUIRE(planes >= 0 && planes <= 65535 && sh >= 1 && sw >= 1, "reflect_pad_upsample12: bad shape");
+    MG_REQUIRE(mx0 >= 0 && mx1 >= 0 && my0 >= 0 && my1 >= 0 && mx0 < sw && mx1 < sw && my0 < sh && my1 < sh,
+               "reflect_pad_upsample12: margins must lie in [0, size - 1]");
+    const int64_t ih = (int64_t)sh + my0 + my1, iw = (int64_t)sw + mx0 + mx1;
+    MG_REQUIRE(4 * ih * iw < (1ll << 31), "reflect_pad_upsample12: plane too large");
+    if (planes == 0) return MG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    MgLaunchScope scope(MG_K_UPFIRDN2D_SEP, st, 4.0 * (double)planes * ((double)sh * sw + 4.0 * (double)ih * iw));
+    SepArgs a;
+    a.x = x; a.f = f; a.y = y; a.ih = (int)ih; a.iw = (int)iw; a.oh = (int)(2 * ih); a.ow = (int)(2 * iw); a.flip = 0; a.gx = gain_axis; a.gy = gain_axis;
+    a.sw = sw; a.sh = sh; a.rx0 = mx0; a.ry0 = my0;
+    // upsample2d's padding for 12 taps: pad0 = (12 + 2 - 1) / 2 = 6 -> q = (1 - 6) & 1 = 1, c = (1 - 6 - 1) >> 1 = -3
+    a.cx = -3; a.cy = -3;
+    const dim3 grid((uint32_t)((a.ow + 63) / 64), (uint32_t)((a.oh + 63) / 64), (uint32_t)planes);
+    hipLaunchKernelGGL((sep12_up2_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    return mg_check_launch(MG_K_UPFIRDN2D_SEP, "reflect_pad_upsample12");
 }

@@ -284,6 +284,7 @@ class AioTrainer:
 
         def accumulate():
             for round_idx, (real_layer, gen_z, real_list) in enumerate(zip(st.blchw, gen_z_rounds, st.lists)):
+                self.grad_sync.begin_round(round_idx == rounds - 1)
                 self.loss.accumulate_gradients(phase=phase.name, real_blchw=real_layer, real_list_of_bchw=real_list, gen_z=gen_z,
                                                sync=(round_idx == rounds - 1), gain=phase.interval)
         phase_engine.run_phase(phase, accumulate, self.grad_sync, self.graphs, self.num_gpus, state_fn=lambda: self._phase_state(phase))

@@ -369,9 +369,8 @@ class AugmentPipe(torch.nn.Module):
             else:
                 margins = tuple(int(v) for v in margin.ceil().to(torch.int32).tolist())   # the one host sync
             mx0, my0, mx1, my1 = margins
-            images = torch.nn.functional.pad(input=images, pad=[mx0, mx1, my0, my1], mode='reflect')
-            # x2 upsample with the 12-tap symlet (separable -> two native passes)
-            images = upfirdn2d.upsample2d(x=images, f=self.Hz_geom, up=2)
+            # reflect-pad + x2 upsample with the 12-tap symlet (:315-317): one native launch, the padded image is never written
+            images = upfirdn2d.reflect_pad_upsample2d(images, self.Hz_geom, [mx0, mx1, my0, my1])
             if theta is None:
                 # sample on the output lattice: left @ G_inv @ right
                 left, right, shape = self._sampling_factors(n, ch, height, width, margins)

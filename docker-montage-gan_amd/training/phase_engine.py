@@ -8,9 +8,10 @@ benchmark execute the SAME code:
                         shared by the main and reg phase of a module (:211-222)
   * ``Phase.begin/finish`` zero_grad(set_to_none) + requires_grad toggles, then gradient
                         post-processing and the optimizer step
-  * ``GradSync``        replaces torch DDP.  One flat fp32 buffer per phase, ONE all-reduce(SUM)/N
-                        over RCCL after the last accumulation round (the ``sync`` round upstream,
-                        :302), then ``nan_to_num(nan=0, posinf=1e5, neginf=-1e5)`` on the flat buffer
+  * ``GradSync``        replaces torch DDP.  One persistent flat fp32 buffer per optimizer; all-reduce(SUM)/N
+                        over RCCL of the last accumulation round's gradients (the ``sync`` round upstream,
+                        :302) -- in buckets started from inside the backward pass (eager phases) or as one
+                        call between the two recorded halves of a phase (HIP graphs) --, then ``nan_to_num(nan=0, posinf=1e5, neginf=-1e5)`` on the flat buffer
                         -- one kernel instead of one per parameter (:310-312) -- and scatter back.
                         This is the intended behaviour of the aio loop, whose own DDP wrap is
                         discarded upstream.
@@ -58,11 +59,16 @@ class GradSync:
 
     VERIFY_FIRST = 2        # signature checks per optimizer key; a call COUNT, hence identical on every rank
 
-    def __init__(self, world_size=1, process_group=None, wire_dtype=None):
+    def __init__(self, world_size=1, process_group=None, wire_dtype=None, overlap=None, bucket_bytes=32 << 20):
         self.world_size, self.process_group, self.wire_dtype = world_size, process_group, wire_dtype
+        self.overlap = (world_size > 1) if overlap is None else bool(overlap)       # bucketed exchange behind the backward pass (eager phases)
+        self.bucket_bytes = bucket_bytes
         self._flat = dict()         # key -> persistent flat buffer
         self._layout = dict()       # key -> tuple of (param index, offset, numel) of the gradients packed last
         self._verified = dict()     # key -> number of signature checks done
+        self._plans = dict()        # key -> _BucketPlan (overlapped exchange)
+        self._active = None         # the plan whose backward is running
+        self.buckets_launched_early = 0     # all-reduces started from inside a backward pass (statistics / tests)
 
     # -- stages ------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -124,6 +130,52 @@ class GradSync:
         self.exchange(flat)
         return self.unpack(params, flat, key)
 
+    # -- overlapped exchange ---------------------------------------------------------------------------
+    # DDP's idea without DDP (the reference's own wrap is discarded): the flat buffer is cut into buckets of
+    # ~bucket_bytes in parameter order; a post-accumulate hook per parameter counts a bucket's gradients in during the LAST
+    # accumulation round, and a bucket whose gradients are all final is copied into its range of the flat buffer (one
+    # multi-tensor copy) and all-reduced asynchronously -- RCCL's own stream -- while the backward pass continues towards
+    # the input.  Buckets start strictly from the last to the first, the same order on every rank.  ``finish`` starts what
+    # is left, waits, and hands the flat buffer to ``unpack`` exactly as ``pack`` + ``exchange`` would have.
+    def arm(self, params, key=None):
+        """Call after zero_grad and before the phase's backward passes (eager phases, more than one rank)."""
+        key = id(params) if key is None else key
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = _BucketPlan(self, params, key)
+        flat = self._flat.get(key)
+        if flat is None or flat.numel() < plan.total:
+            flat = self._flat[key] = torch.empty([plan.total], dtype=torch.float32, device=params[0].device)
+        plan.reset(flat)
+        self._active = plan
+        return plan
+
+    def begin_round(self, last):
+        """The loops announce every accumulation round; gradients are final only in the last one."""
+        if self._active is not None:
+            self._active.last_round = bool(last)
+
+    @torch.no_grad()
+    def finish(self, params, key=None):
+        """After the last backward pass: -> the reduced flat buffer (or None when no parameter has a gradient)."""
+        key = id(params) if key is None else key
+        plan, self._active = self._plans[key], None
+        present = [i for i, p in enumerate(params) if p.grad is not None]
+        present = self._agree(params, present, key)
+        if not present:
+            assert not plan.works, 'a bucket was exchanged although no parameter carries a gradient'
+            self._layout[key] = ()
+            return None
+        plan.launch_rest(params)
+        for work, wire, view in plan.works:
+            work.wait()
+            if wire is not None:
+                view.copy_(wire)
+        plan.works = []
+        plan.flat.div_(self.world_size)
+        self._layout[key] = tuple((i, plan.offsets[i], params[i].numel()) for i in present)
+        return plan.flat[:plan.total]
+
     # -- cross-rank agreement ------------------------------------------------------------------------
     def _agree(self, params, present, key):
         """Every rank runs the same phase code, so the SAME parameters carry gradients everywhere (a phase that
@@ -151,6 +203,64 @@ class GradSync:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         return list(range(len(params)))
+
+
+class _BucketPlan:
+    """Fixed offsets of every parameter of one optimizer in its flat buffer, the bucket boundaries and the per-phase progress."""
+
+    def __init__(self, sync, params, key):
+        self.sync, self.params, self.key = sync, params, key
+        self.offsets, off = [], 0
+        for p in params:
+            self.offsets.append(off)
+            off += p.numel()
+        self.total = off
+        self.buckets, members, lo = [], [], 0           # (lo, hi, member indices), in parameter order
+        for i, p in enumerate(params):
+            members.append(i)
+            hi = self.offsets[i] + p.numel()
+            if (hi - lo) * 4 >= sync.bucket_bytes or i == len(params) - 1:
+                self.buckets.append((lo, hi, tuple(members)))
+                members, lo = [], hi
+        self.bucket_of = [b for b, (_, _, m) in enumerate(self.buckets) for _ in m]
+        self.flat, self.works, self.last_round = None, [], False
+        self.counted, self.pending, self.next_bucket = [], [], -1
+        for i, p in enumerate(params):
+            p.register_post_accumulate_grad_hook(lambda p, i=i: self._on_grad(i))
+
+    def reset(self, flat):
+        self.flat, self.works, self.last_round = flat, [], False
+        self.counted = [False] * len(self.params)
+        self.pending = [len(m) for _, _, m in self.buckets]
+        self.next_bucket = len(self.buckets) - 1        # the backward pass reaches the last parameters first
+
+    def _on_grad(self, i):
+        if self.sync._active is not self or not self.last_round or self.counted[i]:
+            return
+        self.counted[i] = True
+        self.pending[self.bucket_of[i]] -= 1
+        while self.next_bucket >= 0 and self.pending[self.next_bucket] == 0:
+            self._launch(self.next_bucket, self.params)
+            self.sync.buckets_launched_early += 1
+
+    @torch.no_grad()
+    def _launch(self, b, params):
+        lo, hi, members = self.buckets[b]
+        have = [i for i in members if params[i].grad is not None]
+        if len(have) < len(members):
+            self.flat[lo:hi].zero_()                    # a parameter without a gradient counts as zeros, as in pack()'s union case
+        if have:
+            torch._foreach_copy_([GradSync._slice(self.flat, params[i], self.offsets[i]) for i in have], [params[i].grad for i in have])
+        view, wire = self.flat[lo:hi], None
+        if self.sync.wire_dtype is not None and self.sync.wire_dtype != view.dtype:
+            wire = view.to(self.sync.wire_dtype)
+        work = torch.distributed.all_reduce(wire if wire is not None else view, group=self.sync.process_group, async_op=True)
+        self.works.append((work, wire, view))
+        self.next_bucket = b - 1
+
+    def launch_rest(self, params):
+        while self.next_bucket >= 0:
+            self._launch(self.next_bucket, params)
 
 
 class Phase(dnnlib.EasyDict):
@@ -230,7 +340,15 @@ def run_phase(phase, accumulate, grad_sync, graphs=None, world_size=1, state_fn=
         # a phase that computes nothing (global_Greg upstream) has nothing to record
         return phase['_flat'] is not None
 
-    if graphs is None:
+    if graphs is None and world_size > 1 and grad_sync.overlap:
+        with torch.autograd.profiler.record_function(phase.name):
+            phase.begin()
+            grad_sync.arm(params, key)
+            accumulate()
+            phase.end_backward()
+            phase['_flat'] = grad_sync.finish(params, key)
+            step()
+    elif graphs is None:
         with torch.autograd.profiler.record_function(phase.name):
             forward_backward()
             grad_sync.exchange(phase['_flat'])

@@ -160,6 +160,7 @@ class Trainer:
 
             def accumulate():
                 for round_idx, (real_img, real_c, gen_z, gen_c) in enumerate(zip(st.img_rounds, st.c_rounds, phase_gen_z, phase_gen_c)):
+                    self.grad_sync.begin_round(round_idx == rounds - 1)
                     self.loss.accumulate_gradients(phase=phase.name, real_img=real_img, real_c=real_c, gen_z=gen_z, gen_c=gen_c,
                                                    sync=(round_idx == rounds - 1), gain=phase.interval)
             phase_engine.run_phase(phase, accumulate, self.grad_sync, self.graphs, self.num_gpus,

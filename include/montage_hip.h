@@ -115,6 +115,12 @@ int mg_upfirdn2d_sep12(const float* x, const float* f, float* y, int64_t planes,
                        int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
                        int32_t up, int32_t padx0, int32_t pady0, int32_t flip, float gain_axis, void* stream);
 
+/* upsample2d(pad(x, [mx0, mx1, my0, my1], mode='reflect'), f, up=2) for a 12-tap f (training/augment.py:315-317) without
+ * materialising the padded image: x [planes, src_h, src_w] -> y [planes, 2 (src_h + my0 + my1), 2 (src_w + mx0 + mx1)],
+ * float32 dense, margins in [0, size - 1].                                                                          */
+int mg_reflect_pad_upsample12(const float* x, const float* f, float* y, int64_t planes, int32_t src_h, int32_t src_w,
+                              int32_t mx0, int32_t mx1, int32_t my0, int32_t my1, float gain_axis, void* stream);
+
 /* Integer index path only (the part that must be bit exact): for each output
  * coordinate o in [0, out_size) writes {in0, count, filter0} as computed on the
  * DEVICE by the same code the kernels use (upfirdn2d.cu:43-48, 60-65).

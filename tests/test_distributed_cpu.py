@@ -68,6 +68,66 @@ def test_grad_sync_mean_nan_scrub_and_missing_grads():
     assert torch.allclose(g0[3], torch.full_like(g0[3], 2.0))         # ranks disagreed on who has a gradient -> union, (4 + 0) / 2
 
 
+def _overlap_worker(rank, world, init_file, out_dir):
+    """The bucketed exchange started from inside the backward pass against pack + exchange + unpack after it: same phase, same
+    data, two accumulation rounds, a parameter no loss touches, tiny buckets so that several start early."""
+    _init(rank, world, init_file)
+    PE = importlib.import_module(f'{PKG}.training.phase_engine')
+    results = []
+    for overlap in (False, True):
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+        unused = torch.nn.Parameter(torch.ones([5]))
+        params = [unused] + list(net.parameters())       # (a parameter without a gradient holds its own bucket -- and, in launch order, the ones before it -- until finish)
+        opt = torch.optim.SGD(params, lr=0.1)
+        phase = PE.Phase(name='toy', module=[net], opt=opt, interval=1)
+        sync = PE.GradSync(world_size=world, overlap=overlap, bucket_bytes=256)
+        data = torch.randn([2, 4, 6], generator=torch.Generator().manual_seed(10 + rank))
+
+        def accumulate():
+            for r in range(2):
+                sync.begin_round(r == 1)
+                net(data[r]).square().mean().backward()
+        for it in range(3):
+            PE.run_phase(phase, accumulate, sync, None, world)
+            grads = [None if p.grad is None else p.grad.clone() for p in params]
+        assert unused.grad is None                                       # nothing touched it: Adam/SGD must skip it, as on one GPU
+        assert (sync.buckets_launched_early > 0) == overlap
+        if overlap:
+            plan = sync._plans[id(opt)]
+            assert len(plan.buckets) >= 3 and sync.buckets_launched_early >= 3 * (len(plan.buckets) - 1)
+            flat = sync._flat[id(opt)]
+            assert all(g is None or (p.grad.data_ptr() >= flat.data_ptr() and p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4) for p, g in zip(params, grads))
+        results.append((grads, [p.detach().clone() for p in params]))
+    for (ga, pa), (gb, pb) in [results]:
+        for a, b in zip(ga, gb):
+            assert (a is None and b is None) or torch.equal(a, b)       # bit-identical gradients ...
+        for a, b in zip(pa, pb):
+            assert torch.equal(a, b)                                     # ... and weights after three steps
+    torch.save(results[1][1], os.path.join(out_dir, f'w{rank}.pt'))
+    # bf16 on the wire through the buckets
+    sync16 = PE.GradSync(world_size=world, overlap=True, bucket_bytes=256, wire_dtype=torch.bfloat16)
+    lin = torch.nn.Linear(4, 4)
+    prm = list(lin.parameters())
+    ph = PE.Phase(name='toy16', module=[lin], opt=torch.optim.SGD(prm, lr=0.0), interval=1)
+
+    def acc16():
+        sync16.begin_round(True)
+        (lin(torch.ones([1, 4])).sum() * float(rank + 1) * 0.3).backward()
+    PE.run_phase(ph, acc16, sync16, None, world)
+    assert torch.allclose(lin.bias.grad, torch.full([4], 0.45), rtol=1e-2)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_bucketed_exchange_behind_backward_equals_exchange_after_it():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_overlap_worker, args=(2, os.path.join(d, 'init'), d), nprocs=2, join=True)
+        w0, w1 = torch.load(os.path.join(d, 'w0.pt')), torch.load(os.path.join(d, 'w1.pt'))
+    for a, b in zip(w0, w1):
+        assert torch.equal(a, b)
+
+
 def _tick_worker(rank, world, init_file, out_dir):
     """What train_aio.py's subprocess_fn does for num_gpus > 1 (reference train_aio.py:404-426): init_process_group,
     training_stats.init_multiprocessing, then the loop through its first ticks -- the statistics all-reduce needs every

@@ -191,6 +191,38 @@ def test_upfirdn2d_sep12_matches_two_passes_and_its_adjoint(native):
             assert err <= 1e-6, f'{kind} {shape} {nm}: {err:.3g}'
 
 
+def test_reflect_pad_upsample_one_launch(native, oracle):
+    """reflect_pad_upsample2d (augment.py:315-317 in one launch, the padded image never written): integer data bit-exact against
+    numpy's reflect padding + the oracle's upfirdn2d; random data, first and second derivatives against the two-op composition."""
+    U = op('upfirdn2d')
+    AU = importlib.import_module(f'{PKG}.training.augment')
+    rng = np.random.RandomState(8)
+    taps = np.asarray([1, -2, 3, -4, 5, 6, 7, -5, 4, -3, 2, -1], dtype=np.float32)
+    for shape, m in (([2, 3, 9, 14], [3, 5, 8, 0]), ([1, 4, 64, 64], [63, 63, 63, 63]), ([2, 2, 40, 33], [0, 0, 0, 0]), ([1, 1, 70, 90], [17, 2, 1, 30])):
+        x = rng.randint(-8, 9, size=shape).astype(np.float32)
+        xp = np.pad(x, [(0, 0), (0, 0), (m[2], m[3]), (m[0], m[1])], mode='reflect')
+        want = oracle.upfirdn2d(xp, np.outer(taps, taps), (2, 2), (1, 1), (6, 5, 6, 5), False, 4.0)
+        before = native.launch_counts()
+        got = U.reflect_pad_upsample2d(T(x).to(DEV), T(taps).to(DEV), m)
+        after = native.launch_counts()
+        assert after['upfirdn2d_sep'] == before['upfirdn2d_sep'] + 1 and sum(after.values()) == sum(before.values()) + 1
+        assert np.array_equal(got.cpu().numpy(), want), (shape, m)
+    f12 = U.setup_filter(AU.wavelets['sym6']).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn([3, 4, 48, 40], device=DEV, generator=g).requires_grad_(True)
+    m = [7, 20, 11, 3]
+    res = []
+    for fused in (True, False):
+        y = U.reflect_pad_upsample2d(x, f12, m) if fused else U.upsample2d(torch.nn.functional.pad(x, m, mode='reflect'), f12, up=2)
+        dy = torch.randn(y.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)).requires_grad_(True)
+        dx, = torch.autograd.grad([y], [x], [dy], create_graph=True)
+        ddy, = torch.autograd.grad([dx.square().sum()], [dy])          # second order: d/d(dy) of |adjoint(dy)|^2
+        res.append((y.detach(), dx.detach(), ddy))
+    for a, b, nm in zip(res[0], res[1], ('y', 'dx', 'ddy')):
+        err = (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+        assert a.shape == b.shape and err <= 1e-5, f'{nm}: {err:.3g}'
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
 def test_upfirdn2d_stream_kernel_bit_exact_and_edges(native, oracle, dtype):
     """The wave-shuffle streaming kernel (up = down = 1, <= 4x4 taps, width >= 48): odd and even row

@@ -196,7 +196,8 @@ def test_batched_weight_preparation_matches_per_layer_expressions(channels_last)
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])      # forward: same arithmetic, deterministic kernels
     for a, b in zip(res[0][2:], res[1][2:]):
         # gradients pass through float atomics (split-K weight gradients in MIOpen, the fused reductions here): equal up to their order
-        assert float((a.float() - b.float()).norm()) <= 2e-3 * float(b.float().norm()) + 1e-12
+        # (bf16 weight gradients are rounded from those sums: a changed order flips single results by one ulp = 2^-8 of the element)
+        assert float((a.float() - b.float()).norm()) <= 4e-3 * float(b.float().norm()) + 1e-12
 
 
 def test_aio_iteration_runs_native_and_updates_weights():
@@ -230,8 +231,8 @@ def test_aio_iteration_runs_native_and_updates_weights():
 
 
 def test_augment_pipe_on_gpu_matches_reference_golden():
-    """Deterministic (debug_percentile) AugmentPipe images on the GPU -- native separable upfirdn2d passes around
-    aten's grid sampler -- against the reference's CPU output; also in the sync-free fixed-margin mode."""
+    """Deterministic (debug_percentile) AugmentPipe images on the GPU -- the one-pass 12-tap resamplers around the native
+    affine warp -- against the reference's CPU output; also in the sync-free fixed-margin and side-stream modes."""
     from test_augment_layout_golden import run_augment_case
     AU = mod('training.augment')
     native = load_pkg().native
@@ -251,7 +252,8 @@ def test_augment_pipe_on_gpu_matches_reference_golden():
                 np.testing.assert_allclose(y.cpu().numpy(), arr[f'c{c["id"]}_y'], rtol=1e-3, atol=1e-3, err_msg=f'{c} fixed={fixed}')
                 n += 1
             after = native.launch_counts()
-            assert n == 6 and after['upfirdn2d_tiled'] + after['upfirdn2d_stream'] + after['upfirdn2d_generic'] >= before['upfirdn2d_tiled'] + before['upfirdn2d_stream'] + before['upfirdn2d_generic'] + 2 * n       # up and down resampling: one fused separable launch each
+            # reflect-pad + upsampling and the downsampling: ONE one-pass separable launch each (csrc/upfirdn2d_sep.hip)
+            assert n == 6 and after['upfirdn2d_sep'] == before['upfirdn2d_sep'] + 2 * n
     finally:
         AU.fixed_margin = AU.side_stream_margin = False
         GS.enabled = False
@@ -390,3 +392,45 @@ def test_base_trainer_config2_shapes_on_gpu(graphs):
             assert t.graphs.captured + len(t.graphs.rejected) >= 4 and t.graphs.replays >= 2 * 2, (t.graphs.captured, t.graphs.rejected)
     finally:
         AU.fixed_margin = AU.side_stream_margin = False
+
+
+def test_bucketed_gradient_exchange_on_the_device():
+    """GradSync's overlapped exchange on a real GPU: the hooks run on autograd's device thread, the all-reduce is RCCL's
+    (backend "nccl", a one-rank group -- the sum over one rank is the identity, so the result must equal the plain path) and the optimizer step waits for it on the launch stream.  world_size = 2 is only what selects the code path."""
+    import os
+    import tempfile
+    load_pkg()
+    PE = mod('training.phase_engine')
+    dev = torch.device(DEV)
+    with tempfile.TemporaryDirectory() as d:
+        if not torch.distributed.is_initialized():
+            torch.distributed.init_process_group('nccl', init_method='file://' + os.path.join(d, 'init'), rank=0, world_size=1)
+        try:
+            results = []
+            for overlap in (False, True):
+                torch.manual_seed(0)
+                net = torch.nn.Sequential(torch.nn.Conv2d(4, 32, 3, padding=1), torch.nn.LeakyReLU(0.2), torch.nn.Conv2d(32, 32, 3, padding=1),
+                                          torch.nn.LeakyReLU(0.2), torch.nn.Conv2d(32, 4, 3, padding=1)).to(dev)
+                params = list(net.parameters())
+                opt = torch.optim.SGD(params, lr=0.05)
+                phase = PE.Phase(name='toy', module=[net], opt=opt, interval=1)
+                sync = PE.GradSync(world_size=1, overlap=overlap, bucket_bytes=4096)
+                data = torch.randn([2, 8, 4, 32, 32], generator=torch.Generator().manual_seed(3)).to(dev)
+
+                def accumulate():
+                    for r in range(2):
+                        sync.begin_round(r == 1)
+                        net(data[r]).square().mean().backward()
+                for it in range(3):
+                    if overlap:
+                        PE.run_phase(phase, accumulate, sync, None, 2)
+                    else:
+                        PE.run_phase(phase, accumulate, sync, None, 1)
+                torch.cuda.synchronize()
+                assert (sync.buckets_launched_early > 0) == overlap
+                results.append(([p.grad.clone() for p in params], [p.detach().clone() for p in params]))
+            # (the library's weight-gradient kernels sum through float atomics: equal up to their order, not bit for bit)
+            for a, b in zip(results[0][0] + results[0][1], results[1][0] + results[1][1]):
+                assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 1e-12
+        finally:
+            torch.distributed.destroy_process_group()
