@@ -63,15 +63,26 @@ __global__ void __launch_bounds__(256) affine_warp_fwd_kernel(const T* __restric
         const bool vy0 = y0 >= 0 && y0 < hi, vy1 = y0 + 1 >= 0 && y0 + 1 < hi;
         const T* xp = x + (size_t)n * c * ihw;
         T* yp = y + (size_t)n * c * ohw + p;
+        // all 4 x C corner loads go out together from clamped (always valid) addresses; a corner outside the image is dropped by
+        // a select AFTER the load, not a branch around it (zeros padding: what lies at the clamped address must not leak in)
+        const int xa = min(max(x0, 0), wi - 1), xb = min(max(x0 + 1, 0), wi - 1);
+        const size_t ra = (size_t)min(max(y0, 0), hi - 1) * wi, rb = (size_t)min(max(y0 + 1, 0), hi - 1) * wi;
+        float q00[CMAX], q01[CMAX], q10[CMAX], q11[CMAX];
         #pragma unroll
         for (int ch = 0; ch < CMAX; ch++) {
             if (ch >= c) break;
             const T* q = xp + ch * ihw;
+            q00[ch] = to_acc<T>(q[ra + xa]); q01[ch] = to_acc<T>(q[ra + xb]);
+            q10[ch] = to_acc<T>(q[rb + xa]); q11[ch] = to_acc<T>(q[rb + xb]);
+        }
+        #pragma unroll
+        for (int ch = 0; ch < CMAX; ch++) {
+            if (ch >= c) break;
             float v = 0.f;
-            if (vy0 && vx0) v += to_acc<T>(q[(size_t)y0 * wi + x0]) * (wx0 * wy0);
-            if (vy0 && vx1) v += to_acc<T>(q[(size_t)y0 * wi + x0 + 1]) * (wx1 * wy0);
-            if (vy1 && vx0) v += to_acc<T>(q[(size_t)(y0 + 1) * wi + x0]) * (wx0 * wy1);
-            if (vy1 && vx1) v += to_acc<T>(q[(size_t)(y0 + 1) * wi + x0 + 1]) * (wx1 * wy1);
+            v = (vy0 && vx0) ? v + q00[ch] * (wx0 * wy0) : v;
+            v = (vy0 && vx1) ? v + q01[ch] * (wx1 * wy0) : v;
+            v = (vy1 && vx0) ? v + q10[ch] * (wx0 * wy1) : v;
+            v = (vy1 && vx1) ? v + q11[ch] * (wx1 * wy1) : v;
             yp[(size_t)ch * ohw] = from_acc<T>(v);
         }
     }
@@ -81,6 +92,9 @@ __global__ void __launch_bounds__(256) affine_warp_fwd_kernel(const T* __restric
 // pixel o whose source point lies strictly inside (ix-1, ix+1) x (iy-1, iy+1): exactly the corner weights the
 // forward kernel hands out.  Those o lie in the pre-image of that square, a parallelogram centred on
 // M^-1 (p - t) with half extents |M^-1| (1,1)^T; its bounding box on the output lattice is scanned.
+// Measured alternatives at the step's shapes (round 2, 9 calls per step, 366 us per call as below): one workgroup per 32x32 input tile
+// collecting corner weights with LDS float adds -- 870 us (ds_add_f32 is the bottleneck); this gather with uniform trip counts and
+// unconditional loads from clamped addresses -- 570 us (4x the load instructions: bound by the texture path).  Both were dropped.
 template <class T, int CMAX>
 __global__ void __launch_bounds__(256) affine_warp_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ theta,
                                                               T* __restrict__ dx, int c, int hi, int wi, int ho, int wo,

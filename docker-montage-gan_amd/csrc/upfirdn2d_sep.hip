@@ -111,13 +111,24 @@ __global__ void __launch_bounds__(256) sep12_down2_kernel(SepArgs a)
     #pragma unroll
     for (int t = 0; t < 12; t++) fx[t] = tap(a.f, 11 - t, a.flip);
 
-    #pragma unroll 8
-    for (int e = tid; e < TIH * TIW; e += 256) {
+    // the whole tile is requested before the first value is used: the loop below is the only trip to HBM of this workgroup,
+    // and with a partial unroll its (TIH * TIW / 256 =) 23 loads per lane went out in three dependent batches
+    constexpr int NLOAD = (TIH * TIW + 255) / 256;
+    float stage[NLOAD];
+    #pragma unroll
+    for (int it = 0; it < NLOAD; it++) {
+        const int e = tid + it * 256;
         const int r = e / TIW, c = e - r * TIW;
         const int gy = iy0 + r, gx = ix0 + c;
-        float v = 0.f;
-        if ((unsigned)gy < (unsigned)a.ih && (unsigned)gx < (unsigned)a.iw) v = xp[(size_t)gy * a.iw + gx];
-        s_in[r * PITCH + c] = v;
+        const bool ok = e < TIH * TIW && (unsigned)gy < (unsigned)a.ih && (unsigned)gx < (unsigned)a.iw;
+        const float v = xp[ok ? (size_t)gy * a.iw + gx : 0];        // unconditional load (index 0 is always inside the plane)
+        stage[it] = ok ? v : 0.f;
+    }
+    #pragma unroll
+    for (int it = 0; it < NLOAD; it++) {
+        const int e = tid + it * 256;
+        const int r = e / TIW, c = e - r * TIW;
+        if (e < TIH * TIW) s_in[r * PITCH + c] = stage[it];
     }
     __syncthreads();
 

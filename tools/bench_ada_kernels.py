@@ -56,8 +56,8 @@ with torch.no_grad():
                   f'adjoint of upsample2d {list(big.shape)} one_pass={on}')
         U.sep12_enabled = True
         # warp: 2x-upsampled padded image -> 2 * (256 + 12) window, random rotations
-        ang = torch.rand([n], device=dev) * 6.283
-        theta = torch.stack([torch.cos(ang), -torch.sin(ang), torch.zeros_like(ang), torch.sin(ang), torch.cos(ang), torch.zeros_like(ang)], 1) * 0.4
+        ang = torch.rand([n], device=dev, generator=torch.Generator(device=dev).manual_seed(1)) * 6.283        # fixed draw: the cost depends on the angles
+        theta = torch.stack([torch.cos(ang), -torch.sin(ang), torch.zeros_like(ang), torch.sin(ang), torch.cos(ang), torch.zeros_like(ang)], 1) * (ho_ratio := 536 / (2 * (256 + 2 * m)))
         theta = theta.reshape(n, 2, 3).contiguous()
         src = big.requires_grad_(True)
         ho = wo = 2 * (256 + 12)
