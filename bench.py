@@ -411,7 +411,7 @@ def main():
                        'layout': f'{args.layout} in the {args.dtype} blocks (fp16_channels_last)' if args.dtype != 'fp32' else 'nchw',
                        'conv_solver_selection': {'tuned': 'MIOpen immediate mode over the find-db shipped in tuning/miopen', 'immediate': 'MIOpen immediate-mode heuristics',
                                                  'find': 'MIOpen exhaustive find in this run'}[args.miopen],
-                       'parallelism': f'dp{world} (one flat-buffer RCCL all-reduce per phase)',
+                       'parallelism': f'dp{world} (per phase: gradient mean over RCCL through one persistent flat buffer per optimizer -- ' + ('bucketed, started from inside the backward pass' if args.graphs != 'on' else 'one all-reduce between the two recorded halves of the phase') + ')',
                        'phase_graphs': (dict(recorded_and_verified=trainer.graphs.captured, replays=trainer.graphs.replays,
                                             left_eager={str(k): v[:160] for k, v in trainer.graphs.rejected.items()}) if trainer.graphs is not None else 'off'),
                        'hbm_allocated_GB': round(torch.cuda.max_memory_allocated(device) / 1e9, 1),

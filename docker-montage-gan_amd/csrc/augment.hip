@@ -45,7 +45,12 @@ __global__ void __launch_bounds__(256) affine_warp_fwd_kernel(const T* __restric
     const uint32_t tiles_x = ((uint32_t)wo + 15u) >> 4, tiles_y = ((uint32_t)ho + 15u) >> 4, tiles = tiles_x * tiles_y;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t lx = ((wv & 1u) << 3) + (lane & 7u), ly = ((wv >> 1) << 3) + (lane >> 3);
-    for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+    // workgroup ids go round-robin over the 8 XCDs (one L2 each): hand every XCD one contiguous eighth of the tile list, so that
+    // neighbouring tiles -- whose source footprints overlap -- share an L2
+    const uint32_t chunk = (total + 7u) >> 3;
+    for (uint32_t t0 = blockIdx.x; t0 < chunk * 8u; t0 += gridDim.x) {
+        const uint32_t t = (t0 & 7u) * chunk + (t0 >> 3);
+        if (t >= total) continue;
         const uint32_t n = t / tiles, tt = t - n * tiles;
         const uint32_t ty = tt / tiles_x, tx = tt - ty * tiles_x;
         const int oy = (int)(ty * 16u + ly), ox = (int)(tx * 16u + lx);
@@ -106,7 +111,10 @@ __global__ void __launch_bounds__(256) affine_warp_bwd_kernel(const T* __restric
     const uint32_t tiles_x = ((uint32_t)wi + 15u) >> 4, tiles_y = ((uint32_t)hi + 15u) >> 4, tiles = tiles_x * tiles_y;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t lx = ((wv & 1u) << 3) + (lane & 7u), ly = ((wv >> 1) << 3) + (lane >> 3);
-    for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+    const uint32_t chunk = (total + 7u) >> 3;          // XCD-contiguous tile order, as in the forward kernel
+    for (uint32_t t0 = blockIdx.x; t0 < chunk * 8u; t0 += gridDim.x) {
+        const uint32_t t = (t0 & 7u) * chunk + (t0 >> 3);
+        if (t >= total) continue;
         const uint32_t n = t / tiles, tt = t - n * tiles;
         const uint32_t ty = tt / tiles_x, tx = tt - ty * tiles_x;
         const int iy = (int)(ty * 16u + ly), ix = (int)(tx * 16u + lx);
@@ -426,7 +434,7 @@ extern "C" int mg_affine_warp_fwd(const void* x, const float* theta, void* y, in
     MG_REQUIRE((int64_t)n * c * in_h * in_w <= INT32_MAX && (int64_t)n * c * out_h * out_w <= INT32_MAX, "x is too large");
     if (n == 0) return MG_OK;
     const uint32_t total = (uint32_t)n * (((uint32_t)out_w + 15u) >> 4) * (((uint32_t)out_h + 15u) >> 4);      // 16x16-pixel tiles
-    uint32_t blocks = total < 256u * 64u ? total : 256u * 64u;
+    uint32_t blocks = ((total + 7u) & ~7u) < 256u * 64u ? ((total + 7u) & ~7u) : 256u * 64u;        // a multiple of 8: a workgroup keeps its XCD across the stride
     hipStream_t s = (hipStream_t)stream;
     int es = mg_dtype_size(dtype);
     MgLaunchScope scope(MG_K_AFFINE_WARP_FWD, s, ((double)n * c * in_h * in_w + (double)n * c * out_h * out_w) * es);
@@ -446,7 +454,7 @@ extern "C" int mg_affine_warp_bwd(const void* dy, const float* theta, void* dx, 
     MG_REQUIRE((int64_t)n * c * in_h * in_w <= INT32_MAX && (int64_t)n * c * out_h * out_w <= INT32_MAX, "x is too large");
     if (n == 0) return MG_OK;
     const uint32_t total = (uint32_t)n * (((uint32_t)in_w + 15u) >> 4) * (((uint32_t)in_h + 15u) >> 4);        // 16x16-pixel tiles
-    uint32_t blocks = total < 256u * 64u ? total : 256u * 64u;
+    uint32_t blocks = ((total + 7u) & ~7u) < 256u * 64u ? ((total + 7u) & ~7u) : 256u * 64u;        // a multiple of 8: a workgroup keeps its XCD across the stride
     hipStream_t s = (hipStream_t)stream;
     int es = mg_dtype_size(dtype);
     MgLaunchScope scope(MG_K_AFFINE_WARP_BWD, s, ((double)n * c * in_h * in_w + (double)n * c * out_h * out_w) * es);

@@ -32,7 +32,15 @@ __global__ void __launch_bounds__(256) demod_fwd_kernel(const float* __restrict_
         // [kk][I]: lane t owns channels t, t+256, ...; for a fixed tap consecutive lanes read consecutive floats
         for (int i = threadIdx.x; i < ic; i += 256) {
             float a = 0.f;
-            for (int k = 0; k < kk; k++) { const float v = wp[(size_t)k * ic + i]; a = __builtin_fmaf(v, v, a); }
+            if (kk == 9) {          // the 3x3 layers: nine loads in flight instead of nine round trips (the run-time loop is not unrolled)
+                float v[9];
+                #pragma unroll
+                for (int k = 0; k < 9; k++) v[k] = wp[(size_t)k * ic + i];
+                #pragma unroll
+                for (int k = 0; k < 9; k++) a = __builtin_fmaf(v[k], v[k], a);
+            } else {
+                for (int k = 0; k < kk; k++) { const float v = wp[(size_t)k * ic + i]; a = __builtin_fmaf(v, v, a); }
+            }
             s_wsq[i] = a;
             wsq[(size_t)o * ic + i] = a;
         }
@@ -43,7 +51,11 @@ __global__ void __launch_bounds__(256) demod_fwd_kernel(const float* __restrict_
         for (int i0 = 0; i0 < ic; i0 += 256) {
             const int cnt = min(256, ic - i0) * kk;
             const float* src = wp + (size_t)i0 * kk;
-            for (int e = threadIdx.x; e < cnt; e += 256) tile[e] = src[e];
+            float stage[DM_MAXKK];          // cnt <= 256 * DM_MAXKK: every load of the run goes out before the first LDS write
+            #pragma unroll
+            for (int u = 0; u < DM_MAXKK; u++) { const int e = threadIdx.x + u * 256; stage[u] = e < cnt ? src[e] : 0.f; }
+            #pragma unroll
+            for (int u = 0; u < DM_MAXKK; u++) { const int e = threadIdx.x + u * 256; if (e < cnt) tile[e] = stage[u]; }
             __syncthreads();
             const int i = i0 + threadIdx.x;
             if (i < ic) {
@@ -68,7 +80,15 @@ __global__ void __launch_bounds__(256) demod_fwd_kernel(const float* __restrict_
     for (int nn = threadIdx.x >> 3; nn < n; nn += 32) {
         const float* sp = s + (size_t)nn * ic;
         float a = 0.f;
-        for (int i = q; i < ic; i += 8) { const float v = sp[i]; a = __builtin_fmaf(v * v, s_wsq[i], a); }
+        int i = q;
+        for (; i + 56 < ic; i += 64) {          // 8 styles per lane in flight; same summation order as the plain loop
+            float v[8];
+            #pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = sp[i + 8 * u];
+            #pragma unroll
+            for (int u = 0; u < 8; u++) a = __builtin_fmaf(v[u] * v[u], s_wsq[i + 8 * u], a);
+        }
+        for (; i < ic; i += 8) { const float v = sp[i]; a = __builtin_fmaf(v * v, s_wsq[i], a); }
         a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
         if (q == 0) d[(size_t)nn * o_total + o] = 1.f / sqrtf(a + 1e-8f);
     }
@@ -90,7 +110,15 @@ __global__ void __launch_bounds__(256) demod_bwd_w_kernel(const float* __restric
     __syncthreads();
     for (int i = threadIdx.x; i < ic; i += 256) {
         float a = 0.f;
-        for (int nn = 0; nn < n; nn++) { const float v = s[(size_t)nn * ic + i]; a = __builtin_fmaf(s_t[nn], v * v, a); }
+        int nn = 0;
+        for (; nn + 8 <= n; nn += 8) {          // 8 samples in flight, summed in the plain loop's order
+            float v[8];
+            #pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = s[(size_t)(nn + u) * ic + i];
+            #pragma unroll
+            for (int u = 0; u < 8; u++) a = __builtin_fmaf(s_t[nn + u], v[u] * v[u], a);
+        }
+        for (; nn < n; nn++) { const float v = s[(size_t)nn * ic + i]; a = __builtin_fmaf(s_t[nn], v * v, a); }
         s_a[i] = a * 2.f;
     }
     __syncthreads();

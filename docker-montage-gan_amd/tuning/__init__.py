@@ -4,7 +4,8 @@
 (`python bench.py --miopen-find --miopen-db-out DIR`, ~14 minutes on a fresh MI355X) over the convolution
 problems of the benchmark workload (256x256 RGBA, bf16 NHWC blocks + fp32 NCHW blocks) at per-GPU batch 32 (BASELINE configs 2-4;
 140 problems, round 1) and, appended by a second search seeded with those files, at per-GPU batch 4 (BASELINE config 5: global batch
-32 over 8 GPUs; +138 problems, round 2: 470 -> 419 ms per eager step at batch 4).  Other batches miss the db and get MIOpen's heuristics.  They are
+32 over 8 GPUs; +138 problems, round 2: 470 -> 419 ms per eager step at batch 4) and 16 and 8 (BASELINE config 3 and the sizes
+between; +123 problems: 467 -> 414 ms and 374 -> 309 ms per recorded step).  Other batches miss the db and get MIOpen's heuristics.  They are
 measurements of MIOpen's own solvers on gfx950 -- which solver is fastest for which problem -- not code.
 
 `use_tuned_miopen_db()` points MIOpen at a private copy of those files (MIOPEN_USER_DB_PATH).  MIOpen's
