@@ -23,6 +23,7 @@ the step path.
 """
 import contextlib
 import gc
+import os
 
 import torch
 
@@ -61,7 +62,8 @@ class GradSync:
 
     def __init__(self, world_size=1, process_group=None, wire_dtype=None, overlap=None, bucket_bytes=32 << 20):
         self.world_size, self.process_group, self.wire_dtype = world_size, process_group, wire_dtype
-        self.overlap = (world_size > 1) if overlap is None else bool(overlap)       # bucketed exchange behind the backward pass (eager phases)
+        # bucketed exchange behind the backward pass (eager phases); MG_GRAD_OVERLAP=0 falls back to one all-reduce after it
+        self.overlap = (world_size > 1 and os.environ.get('MG_GRAD_OVERLAP', '1') != '0') if overlap is None else bool(overlap)
         self.bucket_bytes = bucket_bytes
         self._flat = dict()         # key -> persistent flat buffer
         self._layout = dict()       # key -> tuple of (param index, offset, numel) of the gradients packed last

@@ -223,6 +223,32 @@ def test_reflect_pad_upsample_one_launch(native, oracle):
         assert a.shape == b.shape and err <= 1e-5, f'{nm}: {err:.3g}'
 
 
+def test_ada_resamplers_full_size_adjoint_pairs(native):
+    """At the benchmark's sizes (batch 32, RGBA, 256^2 with its margins) the oracle is too slow; the size-independent property of a
+    linear map and its gradient is <A x, y> = <x, A^T y>.  Checked for the one-pass upsampler (with the folded reflect padding), the
+    downsampler, and the affine warp between them, with float64 dot products: 1e-5 of |Ax||y|."""
+    U, W = op('upfirdn2d'), op('affine_warp')
+    AU = importlib.import_module(f'{PKG}.training.augment')
+    f12 = U.setup_filter(AU.wavelets['sym6']).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    ang = torch.rand([32], device=DEV, generator=g) * 6.283
+    theta = (torch.stack([torch.cos(ang), -torch.sin(ang), torch.zeros_like(ang), torch.sin(ang), torch.cos(ang), torch.zeros_like(ang)], 1) * 0.8).reshape(32, 2, 3)
+    maps = (('reflect pad + upsample', [32, 4, 256, 256], lambda x: U.reflect_pad_upsample2d(x, f12, [31, 33, 32, 30])),
+            ('downsample', [32, 4, 536, 536], lambda x: U.downsample2d(x, f12, down=2, padding=-12, flip_filter=True)),
+            ('affine warp', [32, 4, 640, 640], lambda x: W.affine_warp(x, theta, 536, 536)))
+    for name, shape, fn in maps:
+        x = torch.randn(shape, device=DEV, generator=g).requires_grad_(True)
+        before = native.launch_counts()
+        ax = fn(x)
+        y = torch.randn(ax.shape, device=DEV, generator=g)
+        aty, = torch.autograd.grad([ax], [x], [y])
+        after = native.launch_counts()
+        assert sum(after.values()) == sum(before.values()) + 2, f'{name}: one native launch forward, one backward'
+        lhs, rhs = (ax.detach().double() * y.double()).sum().item(), (x.detach().double() * aty.double()).sum().item()
+        scale = ax.detach().double().norm().item() * y.double().norm().item()
+        assert abs(lhs - rhs) <= 1e-5 * scale, f'{name}: <Ax,y> = {lhs:.9g}, <x,A^T y> = {rhs:.9g}'
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
 def test_upfirdn2d_stream_kernel_bit_exact_and_edges(native, oracle, dtype):
     """The wave-shuffle streaming kernel (up = down = 1, <= 4x4 taps, width >= 48): odd and even row
