@@ -463,8 +463,15 @@ class PhaseGraphs:
     ``share_pool=True`` lets the graphs reuse each other's scratch memory (they replay strictly one after another).
     """
 
-    def __init__(self, device, warmup=1, verify=True, verify_tol=0.02, verify_tol_loose=0.5, share_pool=False, verify_replays=3):
+    # Phases never recorded.  `global_Gmain` (all generators forward and backward, STN, composite, D: the largest recording of the
+    # loop) has been seen to pass its verification replays on a small configuration and still hand back different gradients in a
+    # later replay (DESIGN 5b, unresolved): it is the one phase whose replays are not trusted, so it always runs eagerly.
+    NEVER_RECORDED = ('global_Gmain',)
+
+    def __init__(self, device, warmup=1, verify=True, verify_tol=0.02, verify_tol_loose=0.5, share_pool=False, verify_replays=3,
+                 never_record=NEVER_RECORDED):
         self.device = torch.device(device)
+        self.never_record = tuple(never_record)
         self.warmup, self.verify, self.verify_tol, self.verify_tol_loose = warmup, verify, verify_tol, verify_tol_loose
         self.verify_replays = verify_replays
         self._seen = dict()         # key -> eager executions so far
@@ -529,6 +536,10 @@ class PhaseGraphs:
             self.replays += 1
             return True
         if key in self.rejected:
+            fn()
+            return False
+        if (key[0] if isinstance(key, tuple) else key) in self.never_record:
+            self.rejected[key] = 'not recorded: its replays are not trusted (PhaseGraphs.NEVER_RECORDED)'
             fn()
             return False
         n = self._seen.get(key, 0) + 1

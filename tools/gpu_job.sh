@@ -2,5 +2,14 @@
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd $R
 O=$R/gpurun_out
-timeout -k 10 600 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "full_size or sep12 or reflect or warp" > $O/r2_parity.log 2>&1
-rc=$?; echo "parity rc=$rc"; tail -12 $O/r2_parity.log
+timeout -k 10 900 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "nhwc_fused or fused_backward or channels_last" > $O/r2_parity.log 2>&1
+rc=$?; echo "tests rc=$rc"; tail -3 $O/r2_parity.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 400 python bench.py --no-cpu-baseline --prof-steps 0 > $O/r2_b32_ws.json 2> $O/r2_b32_ws.err
+echo "b32 rc=$?"; python -c "
+import json,sys
+d=json.loads(open('$O/r2_b32_ws.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])"
+timeout -k 10 300 python bench.py --batch-gpu 4 --no-cpu-baseline --prof-steps 0 > $O/r2_b4_ws.json 2> $O/r2_b4_ws.err
+echo "b4 rc=$?"; python -c "
+import json,sys
+d=json.loads(open('$O/r2_b4_ws.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['config'].get('phase_graphs',{}).get('recorded_and_verified'))"
