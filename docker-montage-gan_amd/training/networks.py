@@ -24,6 +24,7 @@ from ..torch_utils.ops import bias_act
 from ..torch_utils.ops import conv2d_resample
 from ..torch_utils.ops import demod
 from ..torch_utils.ops import fma
+from ..torch_utils.ops import mbstd
 from ..torch_utils.ops import modconv_epilogue
 from ..torch_utils.ops import modconv3x3
 from ..torch_utils.ops import upfirdn2d
@@ -555,14 +556,8 @@ class MinibatchStdLayer(torch.nn.Module):
         self.group_size, self.num_channels = group_size, num_channels
 
     def forward(self, x):
-        n, c, h, w = x.shape
-        g = min(int(self.group_size), n) if self.group_size is not None else n
-        f = self.num_channels
-        y = x.reshape(g, -1, f, c // f, h, w)                   # [G, n/G, F, c, H, W]
-        y = (y - y.mean(dim=0)).square().mean(dim=0)           # variance over the group
-        y = (y + 1e-8).sqrt().mean(dim=[2, 3, 4])              # [n/G, F]
-        y = y.reshape(-1, f, 1, 1).repeat(g, 1, h, w)
-        return torch.cat([x, y], dim=1)
+        # one native launch each way on the GPU (torch_utils/ops/mbstd.py), the aten composition of the reference elsewhere
+        return mbstd.minibatch_std(x, self.group_size, self.num_channels)
 
 
 class DiscriminatorEpilogue(torch.nn.Module):

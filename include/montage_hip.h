@@ -75,6 +75,7 @@ enum {
     MG_K_ADA_PARAMS = 19,
     MG_K_MODCONV = 20,
     MG_K_UPFIRDN2D_SEP = 21,
+    MG_K_MBSTD = 22,
     MG_K_COUNT = 24
 };
 
@@ -290,6 +291,13 @@ int mg_filtered_lrelu(const void* x, const void* b, const float* fu, const float
                       int32_t fu_h, int32_t fu_w, int32_t fd_h, int32_t fd_w,
                       int up, int down, int padx0, int pady0,
                       float alpha, float gain, float clamp, int flip, void* stream);
+
+/* ---- minibatch standard deviation (training/networks.py:667-691) ---------------------------------------------------------
+ * x [N, C, HW] float32 dense -> out [N, C + F, HW] = cat([x, y]): y[s, f] = mean over the c = C / F channels of block f and the
+ * HW pixels of sqrt(var over the `group` samples {m, m + N/group, ...} of sample s's group + 1e-8).  mg_mbstd_bwd: the gradient
+ * w.r.t. x from dout [N, C + F, HW] and x (mean and sigma are recomputed).  group <= 16, N % group == 0, C % F == 0.        */
+int mg_mbstd_fwd(const float* x, float* out, int32_t n, int32_t c, int32_t hw, int32_t group, int32_t f, void* stream);
+int mg_mbstd_bwd(const float* dout, const float* x, float* dx, int32_t n, int32_t c, int32_t hw, int32_t group, int32_t f, void* stream);
 
 #ifdef __cplusplus
 }

@@ -956,6 +956,47 @@ def test_fused_backward_reductions_match_unfused(native, dtype):
 
 
 # --------------------------------------------------------------------------------------------
+# minibatch standard deviation
+
+def test_minibatch_std_one_launch_each_way(native):
+    """mg_mbstd_fwd / mg_mbstd_bwd against the reference composition (training/networks.py:677-690, restated in ops/mbstd._ref) in
+    float64: output, first derivative (one native launch each), and the second-order path (create_graph=True goes through the
+    composition) -- every compiled group size, several channel blocks, ragged pixel counts, a group of identical samples (sigma at
+    its 1e-8 floor)."""
+    M = op('mbstd')
+    g = torch.Generator(device=DEV).manual_seed(23)
+    for shape, group, f in (([32, 512, 4, 4], 4, 1), ([8, 16, 4, 4], 4, 2), ([6, 12, 3, 5], 3, 4), ([2, 8, 4, 4], 4, 1), ([16, 32, 2, 2], 16, 1),
+                            ([8, 520, 4, 4], 8, 1), ([1, 8, 4, 4], 4, 1), ([5, 8, 4, 4], None, 2)):
+        n = shape[0]
+        gg = min(group, n) if group is not None else n
+        x = torch.randn(shape, device=DEV, generator=g)
+        if n >= 2:
+            x[1] = x[0]                      # identical samples inside some group
+        x.requires_grad_(True)
+        native_path = gg in (1, 2, 3, 4, 8, 16)
+        before = native.launch_count(native.K_MBSTD)
+        y = M.minibatch_std(x, group, f)
+        dy = torch.randn(y.shape, device=DEV, generator=g)
+        dx, = torch.autograd.grad([y], [x], [dy])
+        assert native.launch_count(native.K_MBSTD) == before + (2 if native_path else 0), (shape, group)
+        xr = x.detach().double().requires_grad_(True)
+        yr = M._ref(xr, gg, f)
+        rx, = torch.autograd.grad([yr], [xr], [dy.double()])
+        assert y.shape == yr.shape
+        assert (y.double() - yr).abs().max().item() <= 1e-5 * max(1.0, yr.abs().max().item()), (shape, group)
+        assert (dx.double() - rx).abs().max().item() <= 1e-5 * max(1.0, rx.abs().max().item()), (shape, group)
+        # second order, gradient penalty style (fresh samples: next to sigma's floor the float32 composition itself is ill-conditioned)
+        x2 = torch.randn(shape, device=DEV, generator=g).requires_grad_(True)
+        y2 = M.minibatch_std(x2, group, f)
+        g1, = torch.autograd.grad([(y2 * dy).sum()], [x2], create_graph=True)
+        g2, = torch.autograd.grad([g1.square().sum()], [x2])
+        xr2 = x2.detach().double().requires_grad_(True)
+        r1, = torch.autograd.grad([(M._ref(xr2, gg, f) * dy.double()).sum()], [xr2], create_graph=True)
+        r2, = torch.autograd.grad([r1.square().sum()], [xr2])
+        assert (g2.double() - r2).abs().max().item() <= 1e-3 * max(1.0, r2.abs().max().item()), (shape, group)
+
+
+# --------------------------------------------------------------------------------------------
 # conv2d_gradfix: the plain backward's two gradient paths
 
 @pytest.mark.parametrize('channels,res,pad', [(128, 32, 1), (256, 16, 1), (128, 20, 0)])
