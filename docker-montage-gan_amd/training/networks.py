@@ -16,6 +16,8 @@ What is MI355X-specific here (everything else is the callers' arithmetic, unchan
   * reduced precision is a constructor choice (``fp16_dtype``): torch.float16 as upstream, or
     torch.bfloat16 (BASELINE configs; no overflow pre-normalisation needed in bf16).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -29,6 +31,25 @@ from ..torch_utils.ops import modconv_epilogue
 from ..torch_utils.ops import modconv3x3
 from ..torch_utils.ops import upfirdn2d
 from . import weight_prep
+
+# ---- all affine layers of a synthesis network in a few batched launches ---------------------------------------------------------
+# Every SynthesisLayer / ToRGBLayer starts with ``styles = self.affine(w)``: twenty [N,512] x [512,C] products per generator pass,
+# ~10 us each and three more launches each in the backward pass (two products and a bias sum) -- about 2.4 k tiny GEMM launches
+# per training step.  SynthesisNetwork.forward computes them up front instead, one ``baddbmm`` per group of layers with the same
+# width (four groups at 256^2: 512 / 256 / 128 / 64 channels), and hands each layer its row through ``_affine``; autograd's
+# backward of the group is two batched products and one sum.  Same float32 arithmetic per element (a different GEMM kernel: the
+# sums may differ in the last bit).  CPU tensors and layers called outside their network compute ``self.affine(w)`` as before.
+batched_styles = os.environ.get('MG_BATCHED_STYLES', '1') != '0'
+_style_table = None
+
+
+def _affine(layer, w):
+    table = _style_table
+    if table is not None:
+        s = table.pop(id(layer), None)
+        if s is not None:
+            return s
+    return layer.affine(w)
 
 # Module switch: use the fused epilogue op inside SynthesisLayer (GPU tensors only).
 fused_epilogue = True
@@ -273,7 +294,7 @@ class SynthesisLayer(torch.nn.Module):
     def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
         assert noise_mode in ['random', 'const', 'none']
         misc.assert_shape(x, [None, self.weight.shape[1], *_spatial(self.resolution // self.up, self.init_res, self.conv_config_index)])
-        styles = self.affine(w)
+        styles = _affine(self, w)
         noise_raw = None            # unscaled noise; multiplied by noise_strength below (or inside the fused kernel)
         if self.use_noise and noise_mode == 'random':
             noise_raw = torch.randn([x.shape[0], 1, *_spatial(self.resolution, self.init_res, self.conv_config_index)],
@@ -328,7 +349,7 @@ class ToRGBLayer(torch.nn.Module):
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
 
     def forward(self, x, w, fused_modconv=True):
-        styles = self.affine(w) * self.weight_gain
+        styles = _affine(self, w) * self.weight_gain
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
         return bias_act.bias_act(x, weight_prep.get(self.bias, 1, x.dtype), clamp=self.conv_clamp)
 
@@ -441,6 +462,7 @@ class SynthesisNetwork(torch.nn.Module):
             self.num_ws += block.num_conv + (block.num_torgb if res == img_resolution else 0)
             setattr(self, f'b{res}', block)
         self._prep = {}          # force_fp32 -> weight_prep entries (static per network)
+        self._style_plan = {}    # device -> groups of layers whose affine products are batched
 
     def forward(self, ws, **block_kwargs):
         misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
@@ -451,13 +473,46 @@ class SynthesisNetwork(torch.nn.Module):
         entries = self._prep.get(force_fp32)
         if entries is None:
             entries = self._prep[force_fp32] = weight_prep.Plan([e for res in self.block_resolutions for e in getattr(self, f'b{res}').prep_entries(force_fp32)])
+        global _style_table
         with weight_prep.scope(entries):
+            outer = _style_table
+            _style_table = self._all_styles(ws) if (batched_styles and ws.is_cuda) else None
+            try:
+                for res in self.block_resolutions:
+                    block = getattr(self, f'b{res}')
+                    # a block's toRGB shares the w of the next block's first conv
+                    x, img = block(x, img, ws.narrow(1, w_idx, block.num_conv + block.num_torgb), **block_kwargs)
+                    w_idx += block.num_conv
+            finally:
+                _style_table = outer
+        return img
+
+    def _style_groups(self, device):
+        """[(layers, index tensor into ws)] per affine width, in network order (static per network and device)."""
+        key = str(device)
+        groups = self._style_plan.get(key)
+        if groups is None:
+            by_width, w_idx = {}, 0
             for res in self.block_resolutions:
                 block = getattr(self, f'b{res}')
-                # a block's toRGB shares the w of the next block's first conv
-                x, img = block(x, img, ws.narrow(1, w_idx, block.num_conv + block.num_torgb), **block_kwargs)
+                names = [n for n in ('conv0', 'conv1') if hasattr(block, n)] + (['torgb'] if hasattr(block, 'torgb') else [])
+                for j, name in enumerate(names):         # the order SynthesisBlock.forward draws its ws in
+                    layer = getattr(block, name)
+                    if layer.affine.bias is not None and layer.affine.bias_gain == 1 and layer.affine.activation == 'linear':
+                        by_width.setdefault(layer.affine.weight.shape[0], []).append((layer, w_idx + j))
                 w_idx += block.num_conv
-        return img
+            groups = self._style_plan[key] = [([l for l, _ in v], torch.tensor([i for _, i in v], device=device)) for v in by_width.values() if len(v) > 1]
+        return groups
+
+    def _all_styles(self, ws):
+        table = {}
+        for layers, idx in self._style_groups(ws.device):
+            weight = torch.stack([weight_prep.get(l.affine.weight, l.affine.weight_gain, torch.float32) for l in layers])    # [L, C, w_dim]
+            bias = torch.stack([l.affine.bias for l in layers]).unsqueeze(1)                                               # [L, 1, C]
+            x = ws.index_select(1, idx).transpose(0, 1)                                                                    # [L, N, w_dim]
+            for layer, st in zip(layers, torch.baddbmm(bias, x, weight.transpose(1, 2)).unbind(0)):
+                table[id(layer)] = st
+        return table
 
 
 class Generator(torch.nn.Module):

@@ -437,3 +437,41 @@ def test_bucketed_gradient_exchange_on_the_device():
                 assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 1e-12
         finally:
             torch.distributed.destroy_process_group()
+
+
+def test_batched_affine_styles_match_per_layer_products():
+    """SynthesisNetwork._all_styles (one baddbmm per group of equally wide affine layers) against `self.affine(w)` per layer:
+    images, first-order gradients (weights, biases, ws -- incl. a w shared by a ToRGB and the next block's first conv, and distinct
+    ws per layer as under style mixing) and the path-length style double backward."""
+    NW = mod('training.networks')
+    torch.manual_seed(4)
+    G = NW.Generator(z_dim=64, w_dim=64, img_resolution=64, img_channels=4, mapping_kwargs=dict(num_layers=2),
+                     synthesis_kwargs=dict(channel_base=2048, channel_max=64, conv_clamp=256, num_fp16_res=2, fp16_dtype=torch.bfloat16,
+                                           fp16_channels_last=True)).to(DEV).train()
+    z = torch.randn([4, 64], device=DEV)
+    res = []
+    try:
+        for on in (False, True):
+            NW.batched_styles = on
+            for p in G.parameters():
+                p.grad = None
+            ws = G.mapping(z, None, skip_w_avg_update=True)
+            ws = (ws + 0.1 * torch.randn(ws.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))).detach().requires_grad_(True)
+            img = G.synthesis(ws, noise_mode='const')
+            gws, = torch.autograd.grad([img.square().mean()], [ws], retain_graph=True)
+            img.square().mean().backward()
+            first = [img.detach().float(), gws] + [p.grad.clone() for p in G.synthesis.parameters() if p.grad is not None]
+            for p in G.parameters():
+                p.grad = None
+            ws2 = ws.detach().requires_grad_(True)
+            img2 = G.synthesis(ws2, noise_mode='const')
+            gw, = torch.autograd.grad([(img2 * torch.ones_like(img2)).sum()], [ws2], create_graph=True)
+            gw.square().sum(2).mean(1).sqrt().mean().backward()
+            second = [p.grad.clone() for p in G.synthesis.parameters() if p.grad is not None]
+            res.append(first + second)
+    finally:
+        NW.batched_styles = True
+    assert len(res[0]) == len(res[1]) and len(res[0]) > 40
+    for a, b in zip(res[0], res[1]):
+        # bf16 blocks downstream: a last-bit difference of a style can flip single bf16 roundings of the activations
+        assert a.shape == b.shape and float((a.float() - b.float()).norm()) <= 4e-3 * float(b.float().norm()) + 1e-10
