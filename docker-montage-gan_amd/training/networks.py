@@ -41,15 +41,21 @@ from . import weight_prep
 # sums may differ in the last bit).  CPU tensors and layers called outside their network compute ``self.affine(w)`` as before.
 batched_styles = os.environ.get('MG_BATCHED_STYLES', '1') != '0'
 _style_table = None
+# Likewise the per-layer ``torch.randn([N, 1, H, W])`` of noise_mode='random' (13 launches per pass at 256^2): ONE draw for the
+# whole pass, each layer takes its contiguous share.  (Other positions of the generator's sequence than with per-layer draws;
+# both are i.i.d. normal.  CPU tensors keep the per-layer draws.)
+_noise_table = None
 
 
-def _affine(layer, w):
+def _affine(layer, w, gain=None):
+    """styles of `layer` for this pass: its row of the batched product (already multiplied by `gain`), or affine(w) [* gain]."""
     table = _style_table
     if table is not None:
         s = table.pop(id(layer), None)
         if s is not None:
             return s
-    return layer.affine(w)
+    s = layer.affine(w)
+    return s if gain is None else s * gain
 
 # Module switch: use the fused epilogue op inside SynthesisLayer (GPU tensors only).
 fused_epilogue = True
@@ -297,8 +303,10 @@ class SynthesisLayer(torch.nn.Module):
         styles = _affine(self, w)
         noise_raw = None            # unscaled noise; multiplied by noise_strength below (or inside the fused kernel)
         if self.use_noise and noise_mode == 'random':
-            noise_raw = torch.randn([x.shape[0], 1, *_spatial(self.resolution, self.init_res, self.conv_config_index)],
-                                    device=x.device)
+            noise_raw = _noise_table.pop(id(self), None) if _noise_table is not None else None
+            if noise_raw is None or noise_raw.shape[0] != x.shape[0]:
+                noise_raw = torch.randn([x.shape[0], 1, *_spatial(self.resolution, self.init_res, self.conv_config_index)],
+                                        device=x.device)
         if self.use_noise and noise_mode == 'const':
             noise_raw = self.noise_const
         act_gain = self.act_gain * gain
@@ -349,7 +357,7 @@ class ToRGBLayer(torch.nn.Module):
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
 
     def forward(self, x, w, fused_modconv=True):
-        styles = _affine(self, w) * self.weight_gain
+        styles = _affine(self, w, self.weight_gain)
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
         return bias_act.bias_act(x, weight_prep.get(self.bias, 1, x.dtype), clamp=self.conv_clamp)
 
@@ -476,7 +484,10 @@ class SynthesisNetwork(torch.nn.Module):
         global _style_table
         with weight_prep.scope(entries):
             outer = _style_table
+            global _noise_table
+            outer_nz = _noise_table
             _style_table = self._all_styles(ws) if (batched_styles and ws.is_cuda) else None
+            _noise_table = self._all_noise(ws) if (batched_styles and ws.is_cuda and block_kwargs.get('noise_mode', 'random') == 'random') else None
             try:
                 for res in self.block_resolutions:
                     block = getattr(self, f'b{res}')
@@ -484,8 +495,21 @@ class SynthesisNetwork(torch.nn.Module):
                     x, img = block(x, img, ws.narrow(1, w_idx, block.num_conv + block.num_torgb), **block_kwargs)
                     w_idx += block.num_conv
             finally:
-                _style_table = outer
+                _style_table, _noise_table = outer, outer_nz
         return img
+
+    def _all_noise(self, ws):
+        """One normal draw for every noisy layer of the pass: {id(layer): [N, 1, H, W] contiguous share}."""
+        n = int(ws.shape[0])
+        layers = [getattr(getattr(self, f'b{res}'), name) for res in self.block_resolutions for name in ('conv0', 'conv1')
+                  if hasattr(getattr(self, f'b{res}'), name) and getattr(getattr(self, f'b{res}'), name).use_noise]
+        shapes = [_spatial(l.resolution, l.init_res, l.conv_config_index) for l in layers]
+        buf = torch.randn([sum(n * h * w for h, w in shapes)], device=ws.device)
+        table, off = {}, 0
+        for l, (h, w) in zip(layers, shapes):
+            table[id(l)] = buf[off:off + n * h * w].view(n, 1, h, w)
+            off += n * h * w
+        return table
 
     def _style_groups(self, device):
         """[(layers, index tensor into ws)] per affine width, in network order (static per network and device)."""
@@ -499,18 +523,25 @@ class SynthesisNetwork(torch.nn.Module):
                 for j, name in enumerate(names):         # the order SynthesisBlock.forward draws its ws in
                     layer = getattr(block, name)
                     if layer.affine.bias is not None and layer.affine.bias_gain == 1 and layer.affine.activation == 'linear':
-                        by_width.setdefault(layer.affine.weight.shape[0], []).append((layer, w_idx + j))
+                        # ToRGB multiplies its styles by weight_gain (:357): folded into the group's product below
+                        by_width.setdefault(layer.affine.weight.shape[0], []).append((layer, w_idx + j, float(getattr(layer, 'weight_gain', 1.0)) if name == 'torgb' else 1.0))
                 w_idx += block.num_conv
-            groups = self._style_plan[key] = [([l for l, _ in v], torch.tensor([i for _, i in v], device=device)) for v in by_width.values() if len(v) > 1]
+            groups = self._style_plan[key] = [
+                ([l for l, _, _ in v], torch.tensor([i for _, i, _ in v], device=device),
+                 None if all(g == 1.0 for _, _, g in v) else torch.tensor([g for _, _, g in v], dtype=torch.float32, device=device).reshape(-1, 1, 1))
+                for v in by_width.values() if len(v) > 1]
         return groups
 
     def _all_styles(self, ws):
         table = {}
-        for layers, idx in self._style_groups(ws.device):
+        for layers, idx, gains in self._style_groups(ws.device):
             weight = torch.stack([weight_prep.get(l.affine.weight, l.affine.weight_gain, torch.float32) for l in layers])    # [L, C, w_dim]
             bias = torch.stack([l.affine.bias for l in layers]).unsqueeze(1)                                               # [L, 1, C]
             x = ws.index_select(1, idx).transpose(0, 1)                                                                    # [L, N, w_dim]
-            for layer, st in zip(layers, torch.baddbmm(bias, x, weight.transpose(1, 2)).unbind(0)):
+            st_all = torch.baddbmm(bias, x, weight.transpose(1, 2))
+            if gains is not None:
+                st_all = st_all * gains
+            for layer, st in zip(layers, st_all.unbind(0)):
                 table[id(layer)] = st
         return table
 

@@ -9,10 +9,6 @@ timeout -k 10 400 python bench.py --no-cpu-baseline --prof-steps 0 > $O/r2_b32_b
 echo "b32 rc=$?"; python -c "
 import json,sys
 d=json.loads(open('$O/r2_b32_bs.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])"
-MG_BATCHED_STYLES=0 timeout -k 10 400 python bench.py --no-cpu-baseline --prof-steps 0 > $O/r2_b32_bs0.json 2> $O/r2_b32_bs0.err
-echo "b32 off rc=$?"; python -c "
-import json,sys
-d=json.loads(open('$O/r2_b32_bs0.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])"
 timeout -k 10 300 python bench.py --batch-gpu 4 --no-cpu-baseline --prof-steps 0 > $O/r2_b4_bs.json 2> $O/r2_b4_bs.err
 echo "b4 rc=$?"; python -c "
 import json,sys
