@@ -81,3 +81,47 @@ def test_tuned_miopen_db_switch(monkeypatch):
     # every record is "problem=solver:time,workspace,algo;..." text measured on gfx950
     line = open(os.path.join(dst, [f for f in files if f.endswith('.ufdb.txt')][0])).readline()
     assert '=' in line and 'miopenConvolution' in line
+
+
+def test_batched_style_products_follow_the_per_layer_affines():
+    """SynthesisNetwork._all_styles / _all_noise (one product per group of equally wide affine layers, one normal draw per pass;
+    used on device tensors only) evaluated on CPU tensors: every layer's row equals its own ``affine(w)`` -- with the w a ToRGB shares
+    with the next block's first conv, distinct ws per layer index (style mixing) and ToRGB's weight_gain folded in --, the whole
+    forward through the tables equals the per-layer forward, gradients included, and the noise shares are contiguous and of the
+    layers' shapes."""
+    NW = mod('training.networks')
+    torch.manual_seed(0)
+    G = NW.Generator(z_dim=32, w_dim=32, img_resolution=32, img_channels=4, mapping_kwargs=dict(num_layers=2),
+                     synthesis_kwargs=dict(channel_base=512, channel_max=32)).train()
+    S = G.synthesis
+    ws = G.mapping(torch.randn(3, 32), None)
+    ws = (ws + 0.1 * torch.randn_like(ws)).detach().requires_grad_(True)
+    groups = S._style_groups(ws.device)
+    assert sorted(len(l) for l, _, _ in groups) == [2, 9]                      # 32^2, channel_max 32: nine 32-wide affines, two 16-wide
+    assert [i for _, idx, _ in groups for i in idx.tolist()] == [0, 1, 1, 2, 3, 3, 4, 5, 5, 6, 7]
+    table = S._all_styles(ws)
+    for layers, idx, gains in groups:
+        for layer, i in zip(layers, idx.tolist()):
+            want = layer.affine(ws[:, i]) * (layer.weight_gain if isinstance(layer, NW.ToRGBLayer) else 1.0)
+            assert torch.allclose(table[id(layer)], want, atol=1e-6, rtol=1e-5)
+    noise = S._all_noise(ws)
+    assert len(noise) == 7 and all(v.is_contiguous() and v.shape[:2] == (3, 1) for v in noise.values())
+    # whole forward through the tables against the per-layer forward (const noise), with gradients
+    ref = S(ws, noise_mode='const')
+    g_ref = torch.autograd.grad([ref.square().sum()], [ws] + list(S.parameters()), allow_unused=True)
+    NW._style_table = S._all_styles(ws)
+    try:
+        w_idx, x, img = 0, None, None
+        for res in S.block_resolutions:
+            block = getattr(S, f'b{res}')
+            x, img = block(x, img, ws.narrow(1, w_idx, block.num_conv + block.num_torgb), noise_mode='const')
+            w_idx += block.num_conv
+        assert NW._style_table == {}                                            # every prepared row was taken exactly once
+    finally:
+        NW._style_table = None
+    g_got = torch.autograd.grad([img.square().sum()], [ws] + list(S.parameters()), allow_unused=True)
+    assert torch.allclose(img, ref, atol=1e-5, rtol=1e-4)
+    for a, b in zip(g_got, g_ref):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.allclose(a, b, atol=1e-4 * float(b.abs().max()) + 1e-8, rtol=1e-3)
