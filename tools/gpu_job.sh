@@ -2,14 +2,11 @@
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd $R
 O=$R/gpurun_out
-timeout -k 10 900 python -m pytest tests/test_train_step_gpu.py tests/test_hip_parity.py -x -q -m gpu -k "recorded or fused_backward or loss_phase or channels_last or bucketed" > $O/r2_parity.log 2>&1
-rc=$?; echo "tests rc=$rc"; tail -3 $O/r2_parity.log; grep -n "attempt" $O/r2_parity.log | head
-[ $rc -eq 0 ] || exit $rc
-timeout -k 10 400 python bench.py --no-cpu-baseline --prof-steps 0 > $O/r2_b32_zp.json 2> $O/r2_b32_zp.err
-echo "b32 rc=$?"; python -c "
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/r2_smoke.log 2>&1
+echo "smoke rc=$?"; tail -1 $O/r2_smoke.log
+timeout -k 10 400 python bench.py --workload single --no-cpu-baseline > $O/r02_bench_single_b32.json 2> $O/r02_bench_single_b32.err
+echo "single rc=$?"; python -c "
 import json,sys
-d=json.loads(open('$O/r2_b32_zp.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])"
-timeout -k 10 300 python bench.py --batch-gpu 4 --no-cpu-baseline --prof-steps 0 > $O/r2_b4_zp.json 2> $O/r2_b4_zp.err
-echo "b4 rc=$?"; python -c "
-import json,sys
-d=json.loads(open('$O/r2_b4_zp.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['config'].get('phase_graphs',{}).get('recorded_and_verified'), list(d['config'].get('phase_graphs',{}).get('left_eager',{}).keys()))"
+d=json.loads(open('$O/r02_bench_single_b32.json').read().strip().splitlines()[-1]); print(d['metric'], d['ms_per_step'], d['value'], d['roofline']['frac'] if d.get('roofline') else None, d['roofline_mfma']['frac'] if d.get('roofline_mfma') else None, d['config'].get('phase_graphs'))"
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $O/r2_gpu_tests_final.log 2>&1
+rc=$?; echo "gpu tests rc=$rc"; tail -3 $O/r2_gpu_tests_final.log
