@@ -163,6 +163,24 @@ def cpu_baseline(args):
     return out
 
 
+def resolve_batch(args, world):
+    """--global-batch B (strong scaling: B split evenly over the ranks; --gpus 8 --global-batch 32 is BASELINE configs[4]) or
+    --batch-gpu b (weak scaling, default 32 per GPU); then the settings that follow from the per-GPU batch.  -> 'strong' | 'weak'."""
+    scaling = 'weak'
+    if args.global_batch is not None:
+        assert args.batch_gpu is None, '--global-batch and --batch-gpu are exclusive'
+        assert args.global_batch % world == 0, f'--global-batch {args.global_batch} does not divide over {world} ranks'
+        args.batch_gpu = args.global_batch // world
+        scaling = 'strong'
+    if args.batch_gpu is None:
+        args.batch_gpu = 32
+    if args.graphs == 'auto':
+        args.graphs = 'on' if args.batch_gpu <= 16 else 'off'
+    if args.graphs == 'on' and args.ada_margin != 'fixed':
+        args.ada_margin = 'fixed'
+    return scaling
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -208,18 +226,7 @@ def main():
     ap.add_argument('--marker-file', default=None, help='write clock readings at the start/end of the timed region (for cutting a rocprofv3 trace)')
     args = ap.parse_args()
     world_env = int(os.environ.get('WORLD_SIZE', '1'))
-    scaling = 'weak'
-    if args.global_batch is not None:
-        assert args.batch_gpu is None, '--global-batch and --batch-gpu are exclusive'
-        assert args.global_batch % world_env == 0, f'--global-batch {args.global_batch} does not divide over {world_env} ranks'
-        args.batch_gpu = args.global_batch // world_env
-        scaling = 'strong'
-    if args.batch_gpu is None:
-        args.batch_gpu = 32
-    if args.graphs == 'auto':
-        args.graphs = 'on' if args.batch_gpu <= 16 else 'off'
-    if args.graphs == 'on' and args.ada_margin != 'fixed':
-        args.ada_margin = 'fixed'
+    scaling = resolve_batch(args, world_env)
     if args.miopen_find:
         args.miopen = 'find'
     # solver databases must be in place before the first convolution of the process

@@ -125,3 +125,33 @@ def test_batched_style_products_follow_the_per_layer_affines():
         assert (a is None) == (b is None)
         if a is not None:
             assert torch.allclose(a, b, atol=1e-4 * float(b.abs().max()) + 1e-8, rtol=1e-3)
+
+
+def test_bench_batch_resolution_weak_and_strong_scaling():
+    """bench.py: --global-batch splits evenly over the ranks (strong scaling: --gpus 8 --global-batch 32 is BASELINE configs[4],
+    4 per GPU, phase graphs on, fixed ADA margin), --batch-gpu / the default is weak scaling at 32 per GPU (graphs off)."""
+    import argparse
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        bench = importlib.import_module('bench')
+    finally:
+        sys.path.remove(root)
+
+    def ns(**kw):
+        return argparse.Namespace(**{**dict(global_batch=None, batch_gpu=None, graphs='auto', ada_margin='side'), **kw})
+    a = ns(global_batch=32)
+    assert bench.resolve_batch(a, 8) == 'strong' and a.batch_gpu == 4 and a.graphs == 'on' and a.ada_margin == 'fixed'
+    a = ns(global_batch=32)
+    assert bench.resolve_batch(a, 2) == 'strong' and a.batch_gpu == 16 and a.graphs == 'on'
+    a = ns()
+    assert bench.resolve_batch(a, 8) == 'weak' and a.batch_gpu == 32 and a.graphs == 'off' and a.ada_margin == 'side'
+    a = ns(batch_gpu=8, graphs='off')
+    assert bench.resolve_batch(a, 1) == 'weak' and a.batch_gpu == 8 and a.graphs == 'off'
+    for bad in (ns(global_batch=30), ns(global_batch=32, batch_gpu=4)):
+        try:
+            bench.resolve_batch(bad, 8)
+        except AssertionError:
+            continue
+        raise AssertionError('an indivisible or doubly specified batch must be refused')
