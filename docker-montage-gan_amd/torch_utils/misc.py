@@ -149,11 +149,17 @@ def copy_params_and_buffers(src_module, dst_module, require_all=False):
             tensor.copy_(src[name].detach()).requires_grad_(tensor.requires_grad)
 
 
+ddp_sync_listener = None        # set by phase_engine.GradSync while a phase's bucketed gradient exchange is armed
+
+
 @contextlib.contextmanager
 def ddp_sync(module, sync):
-    """Gradient synchronisation switch (misc.py:178-185).  Understands both torch DDP
-    wrappers (``no_sync``) and this repo's flat-buffer reducer (``parallel.GradReducer``)."""
+    """Gradient synchronisation switch (misc.py:178-185): the forward pass run under ``ddp_sync(module, True)`` is the
+    one whose backward pass exchanges `module`'s gradients.  Understands torch DDP wrappers (``no_sync``) and this repo's
+    flat-buffer exchange (``phase_engine.GradSync``, told through ``ddp_sync_listener`` which parameters become final)."""
     assert isinstance(module, torch.nn.Module)
+    if sync and ddp_sync_listener is not None:
+        ddp_sync_listener(module)
     if sync or not hasattr(module, 'no_sync'):
         yield
     else:

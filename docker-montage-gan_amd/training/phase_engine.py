@@ -71,6 +71,7 @@ class GradSync:
         self._plans = dict()        # key -> _BucketPlan (overlapped exchange)
         self._active = None         # the plan whose backward is running
         self.buckets_launched_early = 0     # all-reduces started from inside a backward pass (statistics / tests)
+        self.stale_phases = 0               # phases whose early buckets had to be exchanged again (a loss outside the contract)
 
     # -- stages ------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -134,11 +135,20 @@ class GradSync:
 
     # -- overlapped exchange ---------------------------------------------------------------------------
     # DDP's idea without DDP (the reference's own wrap is discarded): the flat buffer is cut into buckets of
-    # ~bucket_bytes in parameter order; a post-accumulate hook per parameter counts a bucket's gradients in during the LAST
-    # accumulation round, and a bucket whose gradients are all final is copied into its range of the flat buffer (one
-    # multi-tensor copy) and all-reduced asynchronously -- RCCL's own stream -- while the backward pass continues towards
-    # the input.  Buckets start strictly from the last to the first, the same order on every rank.  ``finish`` starts what
-    # is left, waits, and hands the flat buffer to ``unpack`` exactly as ``pack`` + ``exchange`` would have.
+    # ~bucket_bytes in parameter order; a post-accumulate hook per parameter counts a bucket's gradients in, and a bucket
+    # whose gradients are all final is copied into its range of the flat buffer (one multi-tensor copy) and all-reduced
+    # asynchronously -- RCCL's own stream -- while the backward pass continues towards the input.  Buckets start strictly
+    # from the last to the first, the same order on every rank.  ``finish`` starts what is left, waits, and hands the flat
+    # buffer to ``unpack`` exactly as ``pack`` + ``exchange`` would have.
+    # WHEN a gradient is final follows the reference's own contract (training_loop.py:300-305, loss.py:50-59, misc.py:178-185):
+    # a loss calls backward() several times per round (Dmain: generated, then real images; Gboth: main, then path length;
+    # Renderer: generated, then real), and it says which backward is the synchronising one by running that module's FORWARD
+    # under ``misc.ddp_sync(module, sync=True)`` -- with torch DDP that forward is the one whose backward all-reduces.  Here
+    # ``ddp_sync(module, True)`` arms the module's parameters (``sync_forward``); the hook counts a parameter only once it is
+    # armed, i.e. in the first backward pass after its module's synchronising forward.  A module that never runs under
+    # ``ddp_sync(.., True)`` is exchanged from ``finish`` as a whole.  A loss that breaks the contract (another backward into an
+    # armed parameter after its bucket left) is detected by the same hook and the phase falls back to one exchange of the
+    # final gradients from ``finish`` -- late, never wrong.
     def arm(self, params, key=None):
         """Call after zero_grad and before the phase's backward passes (eager phases, more than one rank)."""
         key = id(params) if key is None else key
@@ -150,6 +160,7 @@ class GradSync:
             flat = self._flat[key] = torch.empty([plan.total], dtype=torch.float32, device=params[0].device)
         plan.reset(flat)
         self._active = plan
+        misc.ddp_sync_listener = self.sync_forward
         return plan
 
     def begin_round(self, last):
@@ -157,11 +168,22 @@ class GradSync:
         if self._active is not None:
             self._active.last_round = bool(last)
 
+    def sync_forward(self, module):
+        """``misc.ddp_sync(module, sync=True)`` was entered: the next backward pass into `module`'s parameters is the
+        synchronising one of this phase (see the block comment above)."""
+        plan = self._active
+        if plan is not None and plan.last_round:
+            for p in module.parameters():
+                i = plan.index.get(id(p))
+                if i is not None:
+                    plan.armed[i] = True
+
     @torch.no_grad()
     def finish(self, params, key=None):
         """After the last backward pass: -> the reduced flat buffer (or None when no parameter has a gradient)."""
         key = id(params) if key is None else key
         plan, self._active = self._plans[key], None
+        misc.ddp_sync_listener = None
         present = [i for i, p in enumerate(params) if p.grad is not None]
         present = self._agree(params, present, key)
         if not present:
@@ -169,11 +191,15 @@ class GradSync:
             self._layout[key] = ()
             return None
         plan.launch_rest(params)
-        for work, wire, view in plan.works:
-            work.wait()
-            if wire is not None:
-                view.copy_(wire)
-        plan.works = []
+        plan.wait()
+        if plan.stale:
+            # a gradient changed after its bucket had left (contract broken by the loss): exchange the final values.  Which
+            # hooks fire is a property of the phase's autograd graph -- the same code on every rank -- so every rank takes
+            # this branch together; no agreement round (it would cost a host read-back per phase).
+            self.stale_phases += 1
+            plan.next_bucket = len(plan.buckets) - 1
+            plan.launch_rest(params)
+            plan.wait()
         plan.flat.div_(self.world_size)
         self._layout[key] = tuple((i, plan.offsets[i], params[i].numel()) for i in present)
         return plan.flat[:plan.total]
@@ -225,19 +251,27 @@ class _BucketPlan:
                 self.buckets.append((lo, hi, tuple(members)))
                 members, lo = [], hi
         self.bucket_of = [b for b, (_, _, m) in enumerate(self.buckets) for _ in m]
-        self.flat, self.works, self.last_round = None, [], False
-        self.counted, self.pending, self.next_bucket = [], [], -1
+        self.index = {id(p): i for i, p in enumerate(params)}
+        self.flat, self.works, self.last_round, self.stale = None, [], False, False
+        self.counted, self.armed, self.pending, self.next_bucket = [], [], [], -1
         for i, p in enumerate(params):
             p.register_post_accumulate_grad_hook(lambda p, i=i: self._on_grad(i))
 
     def reset(self, flat):
-        self.flat, self.works, self.last_round = flat, [], False
+        self.flat, self.works, self.last_round, self.stale = flat, [], False, False
         self.counted = [False] * len(self.params)
+        self.armed = [False] * len(self.params)         # set by GradSync.sync_forward (misc.ddp_sync(module, True))
         self.pending = [len(m) for _, _, m in self.buckets]
         self.next_bucket = len(self.buckets) - 1        # the backward pass reaches the last parameters first
 
     def _on_grad(self, i):
-        if self.sync._active is not self or not self.last_round or self.counted[i]:
+        if self.sync._active is not self:
+            return
+        if self.counted[i]:
+            if self.bucket_of[i] > self.next_bucket:    # its bucket is already on the wire with the previous value
+                self.stale = True
+            return
+        if not self.last_round or not self.armed[i]:
             return
         self.counted[i] = True
         self.pending[self.bucket_of[i]] -= 1
@@ -263,6 +297,13 @@ class _BucketPlan:
     def launch_rest(self, params):
         while self.next_bucket >= 0:
             self._launch(self.next_bucket, params)
+
+    def wait(self):
+        for work, wire, view in self.works:
+            work.wait()
+            if wire is not None:
+                view.copy_(wire)
+        self.works = []
 
 
 class Phase(dnnlib.EasyDict):

@@ -73,6 +73,7 @@ def _overlap_worker(rank, world, init_file, out_dir):
     data, two accumulation rounds, a parameter no loss touches, tiny buckets so that several start early."""
     _init(rank, world, init_file)
     PE = importlib.import_module(f'{PKG}.training.phase_engine')
+    misc = importlib.import_module(f'{PKG}.torch_utils.misc')
     results = []
     for overlap in (False, True):
         torch.manual_seed(0)
@@ -87,7 +88,9 @@ def _overlap_worker(rank, world, init_file, out_dir):
         def accumulate():
             for r in range(2):
                 sync.begin_round(r == 1)
-                net(data[r]).square().mean().backward()
+                with misc.ddp_sync(net, r == 1):         # what the losses do: the synchronising forward announces itself
+                    out = net(data[r])
+                out.square().mean().backward()
         for it in range(3):
             PE.run_phase(phase, accumulate, sync, None, world)
             grads = [None if p.grad is None else p.grad.clone() for p in params]
@@ -118,6 +121,107 @@ def _overlap_worker(rank, world, init_file, out_dir):
     assert torch.allclose(lin.bias.grad, torch.full([4], 0.45), rtol=1e-2)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
+
+
+def _several_backward_worker(rank, world, init_file, out_dir):
+    """Round-2 advisor finding: the real losses call backward() more than once per accumulation round (Dmain: generated
+    images, then real images; Gboth; Renderer).  A bucket must not leave before the LAST of them has added its share.
+    Three loss shapes on a toy phase, each against the plain exchange, bit for bit:
+      'contract'  Dmain's shape: backward of a forward run with sync=False, then backward of the sync=True forward
+      'unmarked'  no forward ever runs under ddp_sync(.., True) (the Renderer phase): everything leaves from finish()
+      'broken'    one sync=True forward followed by TWO backward calls (retain_graph): detected, exchanged again"""
+    _init(rank, world, init_file)
+    PE = importlib.import_module(f'{PKG}.training.phase_engine')
+    misc = importlib.import_module(f'{PKG}.torch_utils.misc')
+    data = torch.randn([2, 2, 4, 6], generator=torch.Generator().manual_seed(20 + rank))
+    for shape in ('contract', 'unmarked', 'broken'):
+        results = []
+        for overlap in (False, True):
+            torch.manual_seed(1)
+            net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+            params = list(net.parameters())
+            phase = PE.Phase(name=shape, module=[net], opt=torch.optim.SGD(params, lr=0.1), interval=1)
+            sync = PE.GradSync(world_size=world, overlap=overlap, bucket_bytes=256)
+
+            def accumulate():
+                for r in range(2):
+                    last = r == 1
+                    sync.begin_round(last)
+                    if shape == 'broken':
+                        with misc.ddp_sync(net, last):
+                            out = net(data[r, 0])
+                        out.square().mean().backward(retain_graph=True)
+                        out.abs().mean().backward()
+                    else:
+                        with misc.ddp_sync(net, False):
+                            fake = net(data[r, 0])
+                        fake.square().mean().backward()
+                        with misc.ddp_sync(net, last and shape == 'contract'):
+                            real = net(data[r, 1])
+                        real.abs().mean().backward()
+            for it in range(2):
+                PE.run_phase(phase, accumulate, sync, None, world)
+            results.append(([p.grad.clone() for p in params], [p.detach().clone() for p in params]))
+            if overlap:
+                n_buckets = len(sync._plans[id(phase.opt)].buckets)
+                assert n_buckets >= 3
+                if shape == 'contract':
+                    assert sync.buckets_launched_early >= 2 * (n_buckets - 1) and sync.stale_phases == 0
+                elif shape == 'unmarked':
+                    assert sync.buckets_launched_early == 0 and sync.stale_phases == 0
+                else:
+                    assert sync.stale_phases == 2
+                assert misc.ddp_sync_listener is None
+        (ga, pa), (gb, pb) = results
+        for a, b in zip(ga + pa, gb + pb):
+            assert torch.equal(a, b), shape
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_bucketed_exchange_with_several_backward_calls_per_round():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_several_backward_worker, args=(2, os.path.join(d, 'init'), d), nprocs=2, join=True)
+
+
+def _loss_phase_worker(rank, world, init_file, out_dir):
+    """The real losses on two ranks: one iteration of the base loop (Gmain, Greg, Dmain, Dreg -- Dmain is two backward calls,
+    StyleGAN2Loss) with the exchange started behind the backward pass against the plain exchange after it: bit-identical
+    weights, and buckets did leave early."""
+    _init(rank, world, init_file)
+    TL = importlib.import_module(f'{PKG}.training.training_loop')
+    torch.set_num_threads(2)
+    weights = []
+    for overlap in ('0', '1'):
+        os.environ['MG_GRAD_OVERLAP'] = overlap
+        kw = TL.default_kwargs(num_gpus=world, batch_gpu=2, resolution=16, num_fp16_res=0)
+        for k in ('G_kwargs', 'D_kwargs'):
+            tgt = kw[k].synthesis_kwargs if k == 'G_kwargs' else kw[k]
+            tgt.channel_base, tgt.channel_max = 256, 8
+        kw.G_kwargs.update(z_dim=16, w_dim=16)
+        kw.training_set_kwargs.num_samples = 16
+        kw.data_loader_kwargs = dict(num_workers=0)
+        t = TL.Trainer(rank=rank, device='cpu', random_seed=3, **kw)
+        t.grad_sync.bucket_bytes = 1024
+        t.run_iteration()
+        t.run_iteration()
+        assert t.grad_sync.overlap == (overlap == '1') and t.grad_sync.stale_phases == 0
+        assert (t.grad_sync.buckets_launched_early > 0) == (overlap == '1')
+        weights.append([p.detach().clone() for p in list(t.G.parameters()) + list(t.D.parameters())])
+    os.environ.pop('MG_GRAD_OVERLAP')
+    for a, b in zip(*weights):
+        assert torch.equal(a, b)
+    torch.save(weights[1], os.path.join(out_dir, f'lw{rank}.pt'))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_loss_phases_overlapped_exchange_equals_plain():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_loss_phase_worker, args=(2, os.path.join(d, 'init'), d), nprocs=2, join=True)
+        w0, w1 = torch.load(os.path.join(d, 'lw0.pt')), torch.load(os.path.join(d, 'lw1.pt'))
+    for a, b in zip(w0, w1):
+        assert torch.equal(a, b)                                        # and the ranks agree with each other
 
 
 def test_bucketed_exchange_behind_backward_equals_exchange_after_it():

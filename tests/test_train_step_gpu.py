@@ -436,14 +436,19 @@ def test_bucketed_gradient_exchange_on_the_device():
                 def accumulate():
                     for r in range(2):
                         sync.begin_round(r == 1)
-                        net(data[r]).square().mean().backward()
+                        with mod('torch_utils.misc').ddp_sync(net, False):
+                            first = net(data[r, :4])
+                        first.square().mean().backward()        # (two backward calls per round, as in Dmain)
+                        with mod('torch_utils.misc').ddp_sync(net, r == 1):
+                            second = net(data[r, 4:])
+                        second.square().mean().backward()
                 for it in range(3):
                     if overlap:
                         PE.run_phase(phase, accumulate, sync, None, 2)
                     else:
                         PE.run_phase(phase, accumulate, sync, None, 1)
                 torch.cuda.synchronize()
-                assert (sync.buckets_launched_early > 0) == overlap
+                assert (sync.buckets_launched_early > 0) == overlap and sync.stale_phases == 0
                 results.append(([p.grad.clone() for p in params], [p.detach().clone() for p in params]))
             # (the library's weight-gradient kernels sum through float atomics: equal up to their order, not bit for bit)
             for a, b in zip(results[0][0] + results[0][1], results[1][0] + results[1][1]):
