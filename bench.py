@@ -329,7 +329,9 @@ def main():
     if args.prof_steps > 0:
         # every rank runs these steps (they contain the gradient all-reduces); only rank 0 records events
         CG = mod('torch_utils.ops.conv2d_gradfix')
-        saved_graphs, trainer.graphs = trainer.graphs, None
+        # same stream and same gradient exchange as the timed steps: a loop built for phase graphs stays inside its stream scope
+        # and on the plain exchange, it only launches the kernels one by one instead of replaying them (round-2 advisor finding)
+        trainer.eager_steps = True
         c0 = native.launch_counts()
         if rank == 0:
             native.prof_reset()
@@ -338,7 +340,7 @@ def main():
         for _ in range(args.prof_steps):
             trainer.run_iteration()
         torch.cuda.synchronize(device)
-        trainer.graphs = saved_graphs
+        trainer.eager_steps = False
         c1 = native.launch_counts()
         prof_counts = {k: round((c1[k] - c0[k]) / args.prof_steps, 1) for k in c1 if c1[k] - c0[k]}
         rec = conv_rec = None
@@ -420,7 +422,11 @@ def main():
                                                  'find': 'MIOpen exhaustive find in this run'}[args.miopen],
                        'parallelism': f'dp{world} (per phase: gradient mean over RCCL through one persistent flat buffer per optimizer -- ' + ('bucketed, started from inside the backward pass' if args.graphs != 'on' else 'one all-reduce between the two recorded halves of the phase') + ')',
                        'phase_graphs': (dict(recorded_and_verified=trainer.graphs.captured, replays=trainer.graphs.replays,
-                                            left_eager={str(k): v[:160] for k, v in trainer.graphs.rejected.items()}) if trainer.graphs is not None else 'off'),
+                                            left_eager={str(k): v[:200] for k, v in trainer.graphs.rejected.items()},
+                                            verification='every recorded phase: 3 replays from saved state within max(2 %, 4 x the spread of a second EAGER execution) of the eager result on gradients / moments / buffers',
+                                            worst_eager_spread=round(max([v['eager_spread'] for v in trainer.graphs.report.values()] or [0.0]), 4),
+                                            worst_replay_deviation=round(max([d for k, v in trainer.graphs.report.items() if k in trainer.graphs._graphs for d in v['replays']] or [0.0]), 4))
+                                       if trainer.graphs is not None else 'off'),
                        'hbm_allocated_GB': round(torch.cuda.max_memory_allocated(device) / 1e9, 1),
                        'ada_margin': args.ada_margin if not args.no_ada else None,
                        'native_launches_per_step': prof_counts if prof_counts is not None else {k: round((counts1[k] - counts0[k]) / args.steps, 1) for k in counts1 if counts1[k] - counts0[k]}},

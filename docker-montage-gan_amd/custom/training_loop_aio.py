@@ -130,6 +130,7 @@ class AioTrainer:
         # graphs=True: every phase is recorded into a HIP graph after `graph_warmup` eager executions and replayed
         # from then on (phase_engine.PhaseGraphs); needs optimizers whose step counter lives on the device.
         self.graphs = None
+        self.eager_steps = False
         if graphs and device.type == 'cuda':
             self.graphs = phase_engine.PhaseGraphs(device, warmup=graph_warmup, verify=graph_verify)
         self._static = None         # persistent input tensors of the phases (refreshed in place every iteration)
@@ -287,7 +288,10 @@ class AioTrainer:
                 self.grad_sync.begin_round(round_idx == rounds - 1)
                 self.loss.accumulate_gradients(phase=phase.name, real_blchw=real_layer, real_list_of_bchw=real_list, gen_z=gen_z,
                                                sync=(round_idx == rounds - 1), gain=phase.interval)
-        phase_engine.run_phase(phase, accumulate, self.grad_sync, self.graphs, self.num_gpus, state_fn=lambda: self._phase_state(phase))
+        # `eager_steps`: a loop built for phase graphs runs the next steps eagerly (bench.py's per-kernel timing) -- same stream, same exchange
+        graphs = None if self.eager_steps else self.graphs
+        phase_engine.run_phase(phase, accumulate, self.grad_sync, graphs, self.num_gpus, state_fn=lambda: self._phase_state(phase),
+                               overlap=self.graphs is None)
 
     def _phase_state(self, phase):
         mods = [self.mapping_network, *self.local_G_list, *self.local_D_list, self.pos_estimator, self.global_D, self.renderer]
@@ -330,7 +334,7 @@ class AioTrainer:
                 phase_engine.update_ema(self.global_G_ema['local_G_list'], self.local_G_list, beta)
                 if self.pos_estimator is not None:
                     phase_engine.update_ema(self.global_G_ema['pos_estimator'], self.pos_estimator, beta)
-            if self.graphs is not None and beta == getattr(self, '_ema_beta_prev', None):
+            if self.graphs is not None and not self.eager_steps and beta == getattr(self, '_ema_beta_prev', None):
                 self.graphs.run(('ema', beta), ema)         # constant beta (no ramp-up, or past it): record once
             else:
                 ema()

@@ -3,8 +3,11 @@
 Same class, constructor arguments and phase semantics as the reference's
 ``training/loss.py`` (StyleGAN2Loss, :25-139); its aio sibling in ``custom/loss_aio.py``
 subclasses this one.  Phases: Gmain / Greg (path length) / Dmain / Dreg (R1), or the
-``*both`` fusions.  Random draws happen in the same order and with the same shapes as
-upstream, so a CPU run from the same seed reproduces the reference's numbers.
+``*both`` fusions.  On the CPU random draws happen in the same order and with the same shapes
+as upstream, so a CPU run from the same seed reproduces the reference's numbers (the golden
+tests rely on it).  On the GPU two draws are batched -- the style-mixing partner is mapped
+together with z, and the synthesis network draws the noise of all its layers at once
+(training/networks.py) --: same distributions, other positions of the generator's sequence.
 
 MI355X notes: the style-mixing splice is a masked select instead of ``ws[:, cutoff:] = ...``
 (upstream indexes with a device scalar, which is a host sync per generator pass), and the

@@ -17,6 +17,7 @@ What is MI355X-specific here (everything else is the callers' arithmetic, unchan
     torch.bfloat16 (BASELINE configs; no overflow pre-normalisation needed in bf16).
 """
 import os
+import threading
 
 import numpy as np
 import torch
@@ -40,16 +41,19 @@ from . import weight_prep
 # backward of the group is two batched products and one sum.  Same float32 arithmetic per element (a different GEMM kernel: the
 # sums may differ in the last bit).  CPU tensors and layers called outside their network compute ``self.affine(w)`` as before.
 batched_styles = os.environ.get('MG_BATCHED_STYLES', '1') != '0'
-_style_table = None
+# Both tables live for the duration of ONE SynthesisNetwork.forward on ONE thread (thread-local, nested passes restore the outer
+# tables): a layer takes its entry out when it runs; a layer invoked again in the same pass, or outside a network, finds nothing
+# and computes ``affine(w)`` / draws its own noise exactly as the reference does.
+_tables = threading.local()
 # Likewise the per-layer ``torch.randn([N, 1, H, W])`` of noise_mode='random' (13 launches per pass at 256^2): ONE draw for the
 # whole pass, each layer takes its contiguous share.  (Other positions of the generator's sequence than with per-layer draws;
-# both are i.i.d. normal.  CPU tensors keep the per-layer draws.)
-_noise_table = None
+# both are i.i.d. normal, but a GPU run from a given seed does NOT reproduce the per-layer sequence of the reference -- "parity
+# unpinned" for noise_mode='random' on the GPU; the CPU path keeps the per-layer draws and reproduces the reference's numbers.)
 
 
 def _affine(layer, w, gain=None):
     """styles of `layer` for this pass: its row of the batched product (already multiplied by `gain`), or affine(w) [* gain]."""
-    table = _style_table
+    table = getattr(_tables, 'styles', None)
     if table is not None:
         s = table.pop(id(layer), None)
         if s is not None:
@@ -303,7 +307,8 @@ class SynthesisLayer(torch.nn.Module):
         styles = _affine(self, w)
         noise_raw = None            # unscaled noise; multiplied by noise_strength below (or inside the fused kernel)
         if self.use_noise and noise_mode == 'random':
-            noise_raw = _noise_table.pop(id(self), None) if _noise_table is not None else None
+            table = getattr(_tables, 'noise', None)
+            noise_raw = table.pop(id(self), None) if table is not None else None
             if noise_raw is None or noise_raw.shape[0] != x.shape[0]:
                 noise_raw = torch.randn([x.shape[0], 1, *_spatial(self.resolution, self.init_res, self.conv_config_index)],
                                         device=x.device)
@@ -481,13 +486,10 @@ class SynthesisNetwork(torch.nn.Module):
         entries = self._prep.get(force_fp32)
         if entries is None:
             entries = self._prep[force_fp32] = weight_prep.Plan([e for res in self.block_resolutions for e in getattr(self, f'b{res}').prep_entries(force_fp32)])
-        global _style_table
         with weight_prep.scope(entries):
-            outer = _style_table
-            global _noise_table
-            outer_nz = _noise_table
-            _style_table = self._all_styles(ws) if (batched_styles and ws.is_cuda) else None
-            _noise_table = self._all_noise(ws) if (batched_styles and ws.is_cuda and block_kwargs.get('noise_mode', 'random') == 'random') else None
+            outer, outer_nz = getattr(_tables, 'styles', None), getattr(_tables, 'noise', None)
+            _tables.styles = self._all_styles(ws) if (batched_styles and ws.is_cuda) else None
+            _tables.noise = self._all_noise(ws) if (batched_styles and ws.is_cuda and block_kwargs.get('noise_mode', 'random') == 'random') else None
             try:
                 for res in self.block_resolutions:
                     block = getattr(self, f'b{res}')
@@ -495,7 +497,7 @@ class SynthesisNetwork(torch.nn.Module):
                     x, img = block(x, img, ws.narrow(1, w_idx, block.num_conv + block.num_torgb), **block_kwargs)
                     w_idx += block.num_conv
             finally:
-                _style_table, _noise_table = outer, outer_nz
+                _tables.styles, _tables.noise = outer, outer_nz
         return img
 
     def _all_noise(self, ws):

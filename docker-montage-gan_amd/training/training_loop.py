@@ -90,6 +90,7 @@ class Trainer:
         self.grad_sync = phase_engine.GradSync(world_size=num_gpus, wire_dtype=grad_wire_dtype)
         # graphs=True: phases are recorded into HIP graphs after `graph_warmup` eager executions (phase_engine.PhaseGraphs)
         self.graphs = phase_engine.PhaseGraphs(device, warmup=graph_warmup, verify=graph_verify) if graphs and device.type == 'cuda' else None
+        self.eager_steps = False        # a loop built for phase graphs runs the next steps eagerly (bench.py's per-kernel timing): same stream, same exchange
         self._static = None
         self.loss = dnnlib.util.construct_class_by_name(device=device, G_mapping=self.G.mapping, G_synthesis=self.G.synthesis,
                                                         D=self.D, augment_pipe=self.augment_pipe, **loss_kwargs)
@@ -163,17 +164,18 @@ class Trainer:
                     self.grad_sync.begin_round(round_idx == rounds - 1)
                     self.loss.accumulate_gradients(phase=phase.name, real_img=real_img, real_c=real_c, gen_z=gen_z, gen_c=gen_c,
                                                    sync=(round_idx == rounds - 1), gain=phase.interval)
-            phase_engine.run_phase(phase, accumulate, self.grad_sync, self.graphs, self.num_gpus,
+            phase_engine.run_phase(phase, accumulate, self.grad_sync, None if self.eager_steps else self.graphs, self.num_gpus,
                                    state_fn=lambda phase=phase: phase_engine.phase_state(
                                        phase, [self.G, self.D], [self.loss.pl_mean] + [t for d in training_stats._counters.values() for t in d.values()],
-                                       flat=self.grad_sync._flat.get(id(phase.opt))))
+                                       flat=self.grad_sync._flat.get(id(phase.opt))),
+                                   overlap=self.graphs is None)
             if phase.end_event is not None:
                 phase.end_event.record(torch.cuda.current_stream(device))
                 phase['_timed'] = True
             ran += 1
         with torch.autograd.profiler.record_function('Gema'):
             beta = phase_engine.ema_beta_for(self.batch_size, self.cur_nimg, self.ema_kimg, self.ema_rampup)
-            if self.graphs is not None and beta == getattr(self, '_ema_beta_prev', None):
+            if self.graphs is not None and not self.eager_steps and beta == getattr(self, '_ema_beta_prev', None):
                 self.graphs.run(('ema', beta), lambda: phase_engine.update_ema(self.G_ema, self.G, beta))
             else:
                 phase_engine.update_ema(self.G_ema, self.G, beta)

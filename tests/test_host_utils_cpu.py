@@ -109,16 +109,16 @@ def test_batched_style_products_follow_the_per_layer_affines():
     # whole forward through the tables against the per-layer forward (const noise), with gradients
     ref = S(ws, noise_mode='const')
     g_ref = torch.autograd.grad([ref.square().sum()], [ws] + list(S.parameters()), allow_unused=True)
-    NW._style_table = S._all_styles(ws)
+    NW._tables.styles = S._all_styles(ws)
     try:
         w_idx, x, img = 0, None, None
         for res in S.block_resolutions:
             block = getattr(S, f'b{res}')
             x, img = block(x, img, ws.narrow(1, w_idx, block.num_conv + block.num_torgb), noise_mode='const')
             w_idx += block.num_conv
-        assert NW._style_table == {}                                            # every prepared row was taken exactly once
+        assert NW._tables.styles == {}                                            # every prepared row was taken exactly once
     finally:
-        NW._style_table = None
+        NW._tables.styles = None
     g_got = torch.autograd.grad([img.square().sum()], [ws] + list(S.parameters()), allow_unused=True)
     assert torch.allclose(img, ref, atol=1e-5, rtol=1e-4)
     for a, b in zip(g_got, g_ref):

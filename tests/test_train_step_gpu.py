@@ -271,8 +271,9 @@ def _tiny_aio(graphs, ada, seed=3, **extra):
         kw.augment_kwargs = dict(class_name='training.augment.AugmentPipe', **AU.augpipe_specs['bgc'])
         kw.augment_p = 0.4
     reals = [DS.synthetic_layers(2, 2, 256, seed=5 + i, device=DEV) for i in range(2)]
+    kw.update(extra)
     return TL.AioTrainer(device=DEV, cfg=dict(TL.config, bypass_renderer=True), resident_batches=reals, random_seed=seed,
-                         graphs=graphs, graph_warmup=1, **kw, **extra)
+                         graphs=graphs, graph_warmup=1, **kw)
 
 
 def test_recorded_function_consumes_the_generator_like_eager_code():
@@ -308,20 +309,27 @@ def test_recorded_function_consumes_the_generator_like_eager_code():
 
 @pytest.mark.parametrize('ada', [False, True])
 def test_recorded_phases_equal_the_eager_loop(ada):
-    """phase_engine.PhaseGraphs: the same tiny train_aio run eagerly (twice: the run-to-run spread that float atomics in
-    MIOpen's split-K and the fused reductions cause) and with every phase recorded into a HIP graph after one eager
-    execution.  All consume the device generator in the same order, so the recorded run must sit near that spread.
+    """phase_engine.PhaseGraphs: the same tiny train_aio run eagerly (twice: the run-to-run spread) and with every phase recorded
+    into a HIP graph after one eager execution.  All consume the device generator in the same order, so the recorded run must
+    reproduce the eager one.
 
-    Open issue (NOTES.md): with ADA in the loop the recorded arm has, in about one run out of four on a fresh box, come out with an
-    O(1) deviation of the first replayed gradients (0.57, 0.65) although every phase had passed its three verification replays; the
-    same code passes on the next run.  The recorded arm therefore gets a second attempt, and both results are printed."""
+    What this test had wrong in round 2 (it retried its recorded arm after "O(1) deviations in one run of four"): with the
+    loop's own Adam(beta1 = 0, eps = 1e-8) two EAGER arms from the same seed differ by 0.64-1.09 of the norm of the second
+    iteration's global_D gradients in half of all pairs (profiles/r03_graph_eager_spread_toy.log: six eager arms, three
+    clusters) -- a near-zero gradient takes a +-lr step whose sign is rounding noise, and the global GAN amplifies that.  The
+    deviation never came from the recordings (each phase, replayed from saved state, reproduces its eager execution to 1e-7 on
+    this configuration: profiles/r03_graph_probe_all_toy.log).  Here Adam runs with eps = 1e-3, which keeps the update a smooth
+    function of the gradient: the arms must then agree tightly, and a wrong replay (stale inputs, other random draws, a skipped
+    step) still shows as an O(1) deviation.  No retry."""
     AU = mod('training.augment')
     TS = mod('torch_utils.training_stats')
+    smooth_adam = {k: dict(class_name='torch.optim.Adam', lr=0.0025, betas=[0, 0.99], eps=1e-3)
+                   for k in ('local_G_opt_kwargs', 'local_D_opt_kwargs', 'global_G_opt_kwargs', 'global_D_opt_kwargs')}
 
     def arm(graphs):
         torch.manual_seed(11)
         TS._counters.clear()
-        t = _tiny_aio(graphs, ada)
+        t = _tiny_aio(graphs, ada, **smooth_adam)
         t.run_iteration()
         t.run_iteration()               # graphs: every phase was recorded after its eager run above; the main phases replay here
         torch.cuda.synchronize()
@@ -330,12 +338,16 @@ def test_recorded_phases_equal_the_eager_loop(ada):
             t.run_iteration()
         torch.cuda.synchronize()
         if graphs:
-            # every phase with work was recorded and verified (three replays from the saved state reproduce the eager execution),
-            # or rejected / never recorded and left eager
+            # every phase with work was recorded and verified (an eager re-execution gives the phase's own spread, three replays from
+            # the saved state must reproduce the eager execution within it), or left eager with the reason
             G = t.graphs
             print('recorded', sorted(map(str, G._graphs)), 'rejected', G.rejected)
-            assert G.captured + len(G.rejected) == 2 * 4 + 3 + 1 and G.captured >= 4 and G.replays >= 4 * 4
+            print('verification', {str(k): (f"{v['eager_spread']:.2g}", [f'{d:.2g}' for d in v['replays']]) for k, v in G.report.items()})
+            assert G.captured + len(G.rejected) == 2 * 4 + 3 + 1 and G.replays >= 4 * 4
+            assert not G.rejected, G.rejected                  # float32-accurate toy networks: every phase reproduces, global_Gmain included
             assert 'global_Greg' not in G._graphs and 'global_Greg' not in G.rejected
+            for k, v in G.report.items():
+                assert v['eager_spread'] < 1e-3 and len(v['replays']) == 3 and max(v['replays']) < 1e-3, (k, v)
         w = [p.detach().float().clone() for m in [t.mapping_network, *t.local_G_list, *t.local_D_list, t.pos_estimator, t.global_D]
              for p in m.parameters()]
         ema = [p.detach().float().clone() for p in t.global_G_ema['local_G_list'][0].parameters()]
@@ -349,30 +361,44 @@ def test_recorded_phases_equal_the_eager_loop(ada):
     AU.fixed_margin, AU.side_stream_margin = True, False
     try:
         (w0, e0, s0, g0), (w1, e1, s1, g1) = arm(False), arm(False)
-        # Adam with beta1 = 0 moves every weight by +-lr whatever the gradient's size, so rounding noise on near-zero gradients is
-        # amplified between iterations.  The spread of ONE eager pair is itself noisy (0.1 % ... 5 % of the gradient norm over the
-        # runs of this test): it raises the floor, the constant term is the bound -- a wrong replay (stale inputs, different random
-        # draws, a skipped optimizer step) shows as an O(1) deviation of the gradients; deviations of a few percent are what
-        # PhaseGraphs' own verification (2 % of every update) polices.
-        failures = []
-        for attempt in range(2):
-            w2, e2, s2, g2 = arm(True)
-            assert len(w0) == len(w2) and len(g0) == len(g2)
-            bad = []
-            for name, a, b, c, slack in (('first replayed gradients', g0, g1, g2, 0.15), ('weights', w0, w1, w2, 0.02), ('ema weights', e0, e1, e2, 0.02)):
-                spread, got = dist(a, b), dist(a, c)
-                print(f'attempt {attempt}: {name}: recorded-vs-eager {got:.4g}, eager-vs-eager {spread:.4g}')
-                if not got <= 3 * spread + slack:
-                    bad.append((name, got, spread))
-            assert set(s0) == set(s2)
-            for k in s0:
-                assert float(s0[k][0]) == float(s2[k][0]), k              # same number of reported elements
-            if not bad:
-                break
-            failures.append(bad)
-        assert len(failures) < 2, failures
+        w2, e2, s2, g2 = arm(True)
+        assert len(w0) == len(w2) and len(g0) == len(g2)
+        for name, a, b, c, floor in (('first replayed gradients', g0, g1, g2, 2e-2), ('weights', w0, w1, w2, 1e-3), ('ema weights', e0, e1, e2, 1e-3)):
+            spread, got = dist(a, b), dist(a, c)
+            print(f'{name}: recorded-vs-eager {got:.4g}, eager-vs-eager {spread:.4g}')
+            assert got <= 4 * spread + floor, (name, got, spread)
+        assert set(s0) == set(s2)
+        for k in s0:
+            assert float(s0[k][0]) == float(s2[k][0]), k              # same number of reported elements
     finally:
         AU.fixed_margin = AU.side_stream_margin = False
+
+
+def test_a_phase_that_does_not_reproduce_eagerly_is_not_recorded():
+    """PhaseGraphs measures a phase's own run-to-run spread with a second eager execution from the same state and random
+    draws; a body whose eager executions differ by more than `chaos_tol` of the update (at full width: global_Gmain) cannot be
+    proved against them and stays eager, with the measurement in the reason.  A reproducible body next to it is recorded."""
+    PE = mod('training.phase_engine')
+    graphs = PE.PhaseGraphs(DEV, warmup=1)
+    w = torch.zeros([1000], device=DEV)
+    hidden = torch.zeros([1000], device=DEV)           # state the verification does not know about: consecutive executions differ
+
+    def chaotic():
+        hidden.add_(1.0)
+        w.add_(torch.sin(hidden * torch.arange(1000, device=DEV)))
+
+    def smooth():
+        w.add_(torch.randn([1000], device=DEV))
+
+    state = lambda: [('w', w, True)]
+    with graphs.stream_scope():
+        graphs.run('chaotic', chaotic, state_fn=state)
+        graphs.run('smooth', smooth, state_fn=state)
+        ran = [graphs.run('chaotic', chaotic, state_fn=state), graphs.run('smooth', smooth, state_fn=state)]
+    torch.cuda.synchronize()
+    assert ran == [False, True]
+    assert 'two EAGER executions' in graphs.rejected['chaotic'] and graphs.report['chaotic']['eager_spread'] > 0.25
+    assert graphs.report['smooth']['eager_spread'] == 0 and graphs.report['smooth']['replays'] == [0, 0, 0]
 
 
 @pytest.mark.parametrize('graphs', [False, True])
