@@ -28,6 +28,7 @@ from ..torch_utils.ops import conv2d_resample
 from ..torch_utils.ops import demod
 from ..torch_utils.ops import fma
 from ..torch_utils.ops import mbstd
+from ..torch_utils.ops import torgb
 from ..torch_utils.ops import modconv_epilogue
 from ..torch_utils.ops import modconv3x3
 from ..torch_utils.ops import upfirdn2d
@@ -63,6 +64,8 @@ def _affine(layer, w, gain=None):
 
 # Module switch: use the fused epilogue op inside SynthesisLayer (GPU tensors only).
 fused_epilogue = True
+# Module switch: ToRGB + the cast to the float32 image path as one native pass (channels-last reduced-precision blocks on the GPU).
+fused_torgb = os.environ.get('MG_FUSED_TORGB', '1') != '0'
 
 
 def _default(v, d):
@@ -366,6 +369,14 @@ class ToRGBLayer(torch.nn.Module):
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
         return bias_act.bias_act(x, weight_prep.get(self.bias, 1, x.dtype), clamp=self.conv_clamp)
 
+    def forward_image(self, x, w, fused_modconv=True):
+        """``forward`` followed by the block's cast to the float32 NCHW image path (reference :460-464) -- on the training path of
+        the channels-last reduced-precision blocks one native pass over x (ops/torgb.py) instead of four launches."""
+        if not fused_modconv and fused_torgb and x.is_cuda and x.dtype != torch.float32:
+            styles = _affine(self, w, self.weight_gain)
+            return torgb.torgb(x, weight_prep.get(self.weight, 1, x.dtype), styles, weight_prep.get(self.bias, 1, x.dtype), clamp=self.conv_clamp)
+        return self.forward(x, w, fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
+
 
 class SynthesisBlock(torch.nn.Module):
     """One resolution of the generator: (up-conv) conv, toRGB with skip-summed image (reference :364-466)."""
@@ -445,8 +456,7 @@ class SynthesisBlock(torch.nn.Module):
             misc.assert_shape(img, [None, self.img_channels, *prev])
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == 'skip':
-            y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv)
-            y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)      # image path stays fp32 (:460-464)
+            y = self.torgb.forward_image(x, next(w_iter), fused_modconv=fused_modconv)       # image path stays fp32 (:460-464)
             img = img.add_(y) if img is not None else y
         assert x.dtype == dtype and (img is None or img.dtype == torch.float32)
         return x, img

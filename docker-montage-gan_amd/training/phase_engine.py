@@ -564,6 +564,14 @@ class PhaseGraphs:
         return g
 
     @staticmethod
+    def _same(a, b):
+        """Bitwise-equal contents, a NaN in the same place on both sides included (a statistics counter that holds the sum of a NaN
+        penalty compares unequal to itself under torch.equal)."""
+        if a.is_floating_point():
+            return bool(((a == b) | ((a != a) & (b != b))).all())
+        return torch.equal(a, b)
+
+    @staticmethod
     def _deviation(after, got, before):
         """|after - got| / |after - before| per tensor (float64 accumulation).  Non-finite values count as equal when both
         sides hold the same one at the same place (the R1 penalty of a fully transparent pixel is NaN upstream as well)."""
@@ -648,7 +656,7 @@ class PhaseGraphs:
         if check:
             why = ''
             torch.cuda.synchronize(self.device)
-            moved = [name for (name, _, _), s_, p_ in zip(entries, state, pre) if not torch.equal(s_, p_)]
+            moved = [name for (name, _, _), s_, p_ in zip(entries, state, pre) if not self._same(s_, p_)]
             del pre
             if moved:
                 why = f'{len(moved)} tensors changed during the capture (work outside the recording): ' + ', '.join(moved[:4])

@@ -76,6 +76,7 @@ enum {
     MG_K_MODCONV = 20,
     MG_K_UPFIRDN2D_SEP = 21,
     MG_K_MBSTD = 22,
+    MG_K_TORGB = 23,
     MG_K_COUNT = 24
 };
 
@@ -248,6 +249,25 @@ int mg_modconv3x3_c64(const void* x, const void* w, const float* s, const float*
 /* diagnostics: while `buf` (device memory, uint64[8]) is set, workgroup 0 of mg_modconv3x3_c64 leaves its cycle counts per phase
  * (stage, prefetch issue, MFMA loop, epilogue, store) there; NULL switches it off (tools/bench_modconv.py). */
 void mg_modconv_debug_timing(void* buf);
+
+/*
+ * mg_torgb_nhwc_{fwd,bwd}: the generator's ToRGB layer on channels-last float16 / bfloat16 activations, one pass each way
+ * (reference montage_gan/training/networks.py:343-359 ToRGBLayer.forward -- modulated_conv2d(demodulate=False), training path
+ * :62-88, then bias_act(clamp) -- followed by SynthesisBlock's `y.to(float32, contiguous)`, :460-464):
+ *     y[n,o,p] = float( T( clamp( T( sum_c T(x[n,p,c] * T(s[n,c])) * w[o,c] ) + b[o] ) ) )          T = the activation dtype
+ * x [N,HW,C] (NHWC), w [O,C], s [N,C] float32, b [O] or NULL, y [N,O,HW] float32 (NCHW).  C in {64,128,256,512}, O <= 4.
+ * clamp < 0: none.  Backward: gy [N,O,HW] float32 -> gx [N,HW,C]; with dyc = T(gy) (the linear activation saves no output, so the
+ * reference's bias_act backward masks nothing even under a clamp: bias_act.py:26, bias_act.cu:139-141) the ZERO-FILLED float32
+ * accumulators G [N,O,C] and gb [O] (may be NULL) receive sum_p dyc[n,p,o] * x[n,p,c] and sum_{n,p} dyc[n,p,o];
+ * mg_torgb_bwd_finish turns them into the parameter gradients in one small launch: gw[o,c] = T(sum_n T(s[n,c]) G[n,o,c]),
+ * gs[n,c] = sum_o w[o,c] G[n,o,c] (float32), gb[o] = T(gb32[o]).
+ */
+int mg_torgb_nhwc_fwd(const void* x, const void* w, const float* s, const void* b, float* y, int dtype,
+                      int32_t n, int32_t c, int32_t hw, int32_t o, float clamp, void* stream);
+int mg_torgb_nhwc_bwd(const void* x, const void* w, const float* s, const float* gy, void* gx, float* G, float* gb,
+                      int dtype, int32_t n, int32_t c, int32_t hw, int32_t o, void* stream);
+int mg_torgb_bwd_finish(const float* G, const float* gb32, const float* s, const void* w, void* gw, float* gs, void* gb,
+                        int dtype, int32_t n, int32_t c, int32_t o, void* stream);
 
 /* ---- alpha composite -------------------------------------------------------
  * x: [B, L, 4, H, W] contiguous (RGB + alpha, values nominally in [0,1]);

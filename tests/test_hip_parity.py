@@ -612,6 +612,74 @@ def test_modconv_epilogue_matches_fma_then_bias_act(native, dtype):
             close_lowp(u.float().cpu().numpy(), v.float().cpu().numpy(), dtype, f'grad {nm}')
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_torgb_one_pass_matches_the_four_launches(native, dtype):
+    """ops/torgb.py: ToRGB + the cast to the float32 image path as one native pass against the composition it replaces
+    (channel_scale -> 1x1 convolution -> bias_act(clamp) -> .to(float32)): values, all four first-order gradients, and the
+    gradient of a gradient (create_graph=True runs the differentiable composition inside the same Function).  Integer-valued data
+    makes every product and sum exact in both, so those cases must agree BIT FOR BIT (rounding points included); random data
+    within two ulps.  Ragged pixel counts, 3 and 4 image channels, a clamp that bites."""
+    TG = op('torgb')
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for (n, c, h, w, o, clamp) in [(2, 64, 24, 40, 4, 6.0), (3, 128, 9, 7, 3, None), (2, 256, 16, 16, 4, 2.5), (1, 512, 8, 8, 4, 4.0), (5, 64, 33, 31, 4, 3.0)]:
+        for exact in (True, False):
+            if exact:       # small integers: |x*s| <= 12, |sum| <= 12 * 3 * 512 < 2^15, every value representable in both 16-bit types
+                x = torch.randint(-3, 4, [n, c, h, w], device=DEV, generator=g).to(dtype)
+                wt = torch.randint(-3, 4, [o, c, 1, 1], device=DEV, generator=g).to(dtype)
+                st = torch.randint(-2, 3, [n, c], device=DEV, generator=g).float()
+                b = torch.randint(-3, 4, [o], device=DEV, generator=g).to(dtype)
+                wt = wt * (torch.rand([o, c, 1, 1], device=DEV, generator=g) < 8.0 / c).to(dtype)      # sparse rows keep the sums small
+            else:
+                x = torch.randn([n, c, h, w], device=DEV, generator=g).to(dtype)
+                wt = (torch.randn([o, c, 1, 1], device=DEV, generator=g) / c ** 0.5).to(dtype)
+                st = torch.randn([n, c], device=DEV, generator=g) + 1
+                b = torch.randn([o], device=DEV, generator=g).to(dtype)
+            x = x.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            wt, st, b = wt.requires_grad_(True), st.requires_grad_(True), b.requires_grad_(True)
+            gy = torch.randint(-4, 5, [n, o, h, w], device=DEV, generator=g).float() if exact else torch.randn([n, o, h, w], device=DEV, generator=g)
+            before = native.launch_count(native.K_TORGB)
+            y = TG.torgb(x, wt, st, b, clamp=clamp)
+            g1 = torch.autograd.grad([y], [x, wt, st, b], [gy])
+            assert native.launch_count(native.K_TORGB) == before + 2, 'the native forward and backward passes did not run'
+            assert y.dtype == torch.float32 and y.is_contiguous() and g1[0].is_contiguous(memory_format=torch.channels_last)
+            TG.enabled = False
+            try:
+                y2 = TG.torgb(x, wt, st, b, clamp=clamp)
+                g2 = torch.autograd.grad([y2], [x, wt, st, b], [gy])
+            finally:
+                TG.enabled = True
+            assert native.launch_count(native.K_TORGB) == before + 2
+            what = f'{(n, c, h, w, o, clamp)} exact={exact}'
+            if exact:
+                assert torch.equal(y, y2), what
+                for u, v, nm in zip(g1, g2, 'x w s b'.split()):
+                    # dW / ds of the composition are rounded through a 16-bit dxs / xs; on integer data those are exact too
+                    assert torch.equal(u.float(), v.float()), f'{what}: grad {nm}'
+            else:
+                close_lowp(y.detach().cpu().numpy(), y2.detach().cpu().numpy(), dtype, what + ' fwd')
+                for u, v, nm in zip(g1, g2, 'x w s b'.split()):
+                    # sums of ~h*w*n rounded terms: the two sides round different intermediates (documented in ops/torgb.py)
+                    close_lowp(u.float().cpu().numpy(), v.float().cpu().numpy(), dtype, f'{what}: grad {nm}', tol=4 * LOWP_TOL[dtype])
+    # second order (path-length regularisation shape): d/dx and d/ds of |dy/ds|^2 through both forms
+    n, c, h, w, o = 2, 64, 8, 8, 4
+    x = torch.randn([n, c, h, w], device=DEV, generator=g).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wt = (torch.randn([o, c, 1, 1], device=DEV, generator=g) / 8).to(dtype).requires_grad_(True)
+    st = (torch.randn([n, c], device=DEV, generator=g) + 1).requires_grad_(True)
+    b = torch.zeros([o], device=DEV).to(dtype).requires_grad_(True)
+    noise = torch.randn([n, o, h, w], device=DEV, generator=g)
+    outs = []
+    for flag in (True, False):
+        TG.enabled = flag
+        try:
+            y = TG.torgb(x, wt, st, b, clamp=256)
+            gs, gx = torch.autograd.grad([(y * noise).sum()], [st, x], create_graph=True)       # (y is linear in s and in x)
+            outs.append(torch.autograd.grad([gs.square().sum() + gx.float().square().sum()], [x, wt, st]))
+        finally:
+            TG.enabled = True
+    for u, v, nm in zip(outs[0], outs[1], 'x w s'.split()):
+        close_lowp(u.float().cpu().numpy(), v.float().cpu().numpy(), dtype, f'second order grad {nm}', tol=4 * LOWP_TOL[dtype])
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
 def test_filtered_lrelu_matches_composition(native, dtype):
     FL, U = op('filtered_lrelu'), op('upfirdn2d')
