@@ -2,24 +2,32 @@
 //
 //     y = clamp( act( conv3x3( x * s[n,ci] ) * d[n,co] + noise[n,h,w] * strength + b[co] ) * gain )
 //
-// (reference training/networks.py:37-98 `modulated_conv2d`, training path, followed by the layer's bias_act, :311-313; with
-// s = d = NULL it is the discriminator's conv0 + bias_act, :600-603).  As separate launches that is: the modulation pass
-// (read x, write x*s), the convolution (read, write), the epilogue pass (read, write) -- six trips of the largest activation of
-// the network ([N,64,256,256] bf16, 268 MB at batch 32) through HBM.  Here: read x once, write y once (and the raw convolution
-// output once more when the backward pass will need it).  Bound: HBM (the contraction has 288 FLOP per activation byte; at
-// 64 channels the matrix cores are ~3x faster than the memory system can feed them).
+// (reference training/networks.py:37-98 `modulated_conv2d` followed by the layer's bias_act, :311-313; with s = d = noise = NULL
+// it is the discriminator's conv0 + bias_act, :600-603; with everything NULL and act = linear a plain convolution -- the data
+// gradient of those layers is that, on dy and the flipped, transposed weights).  As separate launches: the modulation pass (read x,
+// write x*s), the convolution (read, write), the epilogue pass (read, write) -- six trips of the largest activation of the network
+// ([N,64,256,256] bf16, 268 MB at batch 32) through HBM.  Here: read x once, write y once.  Bound: HBM (288 FLOP per activation
+// byte; at 64 channels the matrix cores are ~1.6x faster than the memory system can feed them: 4.6k MFMA cycles per 256 pixels
+// per CU against 7.4k cycles for their 64 KB at ~10 B/clk/CU).
 //
-// Layout: NHWC bf16 activations (torch.channels_last), weights [Cout][kh][kw][Cin] bf16 (channels_last of [O,I,3,3]).
-// Decomposition on CDNA4: a persistent grid of one 256-lane workgroup per CU walks 8x32-pixel output tiles.
-//   * the 9 x 64 x 64 weights live in LDS for the whole launch (rows padded to 144 B: conflict-free 16-byte fragment reads);
-//   * the tile's 10 x 34-pixel halo is staged into LDS with the modulation applied on the way (x * s rounded to bf16, as
-//     the reference's `x * styles.to(x.dtype)` rounds it); the NEXT tile's halo is already in flight into registers while this
-//     tile is being multiplied (global-load latency hidden behind the MFMAs);
-//   * each of the 4 waves owns 2 image rows x 32 pixels x 64 output channels = 2 x 2 accumulators of
-//     v_mfma_f32_32x32x16_bf16 with the WEIGHTS as the A operand (rows = output channels) and the pixels as B (columns), so
-//     that a lane ends up with 4 consecutive output channels of one pixel per register quad;
-//   * epilogue in registers on the float32 accumulators rounded to bf16 first (the reference's convolution returns bf16), then
-//     through LDS so that every lane stores full 16-byte pieces of NHWC rows.
+// Round 2's version kept the 9x64x64 weights in LDS (83 KB) and therefore ONE workgroup per CU whose phases -- stage the halo,
+// multiply, epilogue, store -- ran one after the other: 380 us.  This version is built so that TWO workgroups share a CU and
+// cover each other's memory phases:
+//   * the WEIGHTS LIVE IN REGISTERS.  v_mfma_f32_32x32x16_bf16 with the weights as A (rows = output channels): a wave owns one
+//     half of the output channels (32), i.e. 9 taps x 4 k-steps = 36 A fragments of 4 VGPRs = 144 VGPRs for the whole launch --
+//     no LDS for them, no A reads in the loop.  The modulation is folded into them: A = bf16(w * bf16(s[n,ci])), recomputed only
+//     when a workgroup's run of tiles crosses into the next sample (the reference's own `fused_modconv` formulation, :91-93).
+//   * the input halo (6 x 34 pixels for a 4 x 32 tile) goes global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPRs,
+//     out-of-image pixels come back as zeros from the buffer range check), double buffered: the next tile's halo is in flight
+//     while this one is multiplied; one barrier per tile.
+//   * LDS image: 8 pixels x 128 B per 1-KiB DMA piece, 16-byte slots XOR-swizzled over the 256-B bank row (two pixels) with the
+//     pixel-pair index -- applied on the DMA's per-lane SOURCE address and on the ds_read_b128 address alike -- so that the 32
+//     pixels of a B fragment spread over the banks.
+//   * epilogue on the accumulators (a lane holds 4 consecutive output channels of one pixel per register quad), through a
+//     WAVE-PRIVATE 2.5 KB staging strip (no workgroup barrier) into 16-byte stores of 64-byte half pixel rows.
+// LDS per workgroup: 2 x 30 KB halo + 10 KB staging + d / bias = 70.5 KB -> two workgroups per CU; <= 256 VGPRs -> 2 waves/SIMD.
+// Rounding points: the convolution result to bf16, then d (rounded to bf16), the noise fma, the sum to bf16, bias + act + gain +
+// clamp as bias_act -- those of the three-launch path; the modulation is rounded on the weight instead of on the activation.
 #include "mg_common.h"
 #include "mg_act.h"
 
@@ -27,14 +35,17 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
 
-constexpr int MC_C = 64;                 // channels in = channels out
-constexpr int MC_TH = 8, MC_TW = 32;     // output tile (pixels)
-constexpr int MC_HH = MC_TH + 2, MC_HW = MC_TW + 2;      // halo tile
-constexpr int MC_ROW = MC_C + 8;         // LDS row of one pixel / one (tap, co) weight row, in bf16 elements: 144 bytes
-constexpr int MC_W_ELEMS = 9 * MC_C * MC_ROW;            // 41,472 bf16 = 82,944 B
-constexpr int MC_A_ELEMS = MC_HH * MC_HW * MC_ROW;       // 24,480 bf16 = 48,960 B
-constexpr int MC_PRE = (MC_HH * MC_HW * 8 + 255) / 256;  // 16-byte halo pieces per lane (11)
+constexpr int MC_C = 64;
+constexpr int MC_TH = 4, MC_TW = 32;                // output tile (pixels)
+constexpr int MC_HR = MC_TH + 2;                    // halo rows
+constexpr int MC_HROW = 40;                         // pixels per halo row in LDS (34 used; 5 DMA pieces of 8 pixels)
+constexpr int MC_PIECES = MC_HR * MC_HROW / 8;      // 30 pieces of 1 KiB
+constexpr int MC_HALO_BYTES = MC_PIECES * 1024;     // 30,720
+constexpr int MC_STAGE_PX = 80;                     // bytes per pixel of the output staging strip (64 + 16: 16-byte aligned, 2-way on the 8-byte writes)
+constexpr int MC_STAGE_BYTES = 32 * MC_STAGE_PX;    // one 32-pixel block x 32 channels per wave
+constexpr int MC_LDS = 2 * MC_HALO_BYTES + 4 * MC_STAGE_BYTES + 2 * MC_C * 4;      // + d + bias
 
 struct McArgs {
     const mg_bf16* x;        // [N,H,W,64]
@@ -46,201 +57,237 @@ struct McArgs {
     const mg_bf16* b;        // [64] bias (NULL: none)
     mg_bf16* yconv;          // raw convolution output, bf16 (NULL: not wanted)
     mg_bf16* y;              // epilogue output (NULL: not wanted)
-    mg_bf16* xs;             // modulated input x * s, bf16 (NULL: not wanted): what the library's weight gradient reads
-    int n, h, w_;            // batch, height, width
+    int n, h, w_;
     int64_t noise_stride_n;  // 0 = shared noise
-    int act;                 // 1 linear, 3 lrelu
     float alpha, gain, clamp;
-    int tiles_x, tiles_y, tiles;
-    unsigned long long* timing;   // debug: cycles per phase of workgroup 0 (NULL: off)
+    int tiles_x, tiles_y, tiles, per_wg;
+    uint32_t x_bytes;        // N*H*W*128: the buffer range of the DMA
+    unsigned long long* timing;   // diagnostic build only: cycles per phase of wave 0 of workgroup (0, 0)
 };
 
 __device__ __forceinline__ float bf2f(mg_bf16 v) { return to_acc<mg_bf16>(v); }
+__device__ __forceinline__ float rbf(float v) { return bf2f(from_acc<mg_bf16>(v)); }
 
-union Pack8 { uint4 u; mg_bf16 h[8]; };
-
-template <int ACT>
-__global__ void __launch_bounds__(256, 1) modconv3x3_c64_kernel(McArgs p)
+// byte offset of (halo column hx, 16-byte chunk c of the pixel's 64 channels) inside its halo row of the swizzled LDS image: a
+// 256-byte bank row holds two pixels = 16 slots; the slot is XORed with the pixel-pair index OF THE COLUMN, so the address of the
+// row below is this one plus MC_HROW * 128 -- an immediate offset of the ds_read.
+__device__ __forceinline__ uint32_t mc_col_off(uint32_t hx, uint32_t c)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    mg_bf16* wl = (mg_bf16*)smem_raw;                   // [9][64][MC_ROW]
-    mg_bf16* al = wl + MC_W_ELEMS;                      // [MC_HH][MC_HW][MC_ROW]; reused as the output staging [256][MC_ROW]
-    float* dl = (float*)(al + MC_A_ELEMS);              // [64] demodulation of the current sample
-    float* bl = dl + MC_C;                              // [64] bias
+    const uint32_t pair = hx >> 1, slot = (((hx & 1u) << 3) | c) ^ (pair & 15u);
+    return pair * 256u + slot * 16u;
+}
+
+#define LDS_ __attribute__((address_space(3)))
+typedef float f2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_bf16(f2_t v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }      // v_cvt_pk_bf16_f32
+__device__ __forceinline__ f2_t unpk_bf16(uint32_t u) { f2_t r; r.x = __builtin_bit_cast(float, u << 16); r.y = __builtin_bit_cast(float, u & 0xFFFF0000u); return r; }
+__device__ __forceinline__ f2_t rbf2(f2_t v) { return unpk_bf16(pk_bf16(v)); }
+
+template <int ACT, bool MOD, bool DBG>
+__global__ void __launch_bounds__(256, 2) modconv3x3_c64_kernel(McArgs p)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* const halo = smem;                                   // [2][30 KiB]
+    unsigned char* const stage = smem + 2 * MC_HALO_BYTES;              // [4 waves][2,560 B]
+    LDS_ float* const dl = (LDS_ float*)(stage + 4 * MC_STAGE_BYTES);   // [64] demodulation of the workgroup's sample
+    LDS_ float* const bl = dl + MC_C;                                    // [64] bias
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int c8 = tid & 7;                             // this lane's 8-channel piece in every staging step (256 % 8 == 0)
+    const int ob = wave & 1, rh = wave >> 1;                            // this wave: output channels ob*32.., tile rows rh*2, rh*2+1
 
-    // ---- weights -> LDS, once per launch: [co][tap][ci] in memory -> [tap][co][ci (+pad)] in LDS
-    for (int e = tid; e < 9 * MC_C * 8; e += 256) {
-        const int piece = e & 7, rowi = e >> 3;         // rowi = co * 9 + tap
-        const int co = rowi / 9, tap = rowi - co * 9;
-        const uint4 v = *(const uint4*)(p.w + (size_t)rowi * MC_C + piece * 8);
-        *(uint4*)(wl + ((size_t)tap * MC_C + co) * MC_ROW + piece * 8) = v;
-    }
-    if (tid < MC_C) bl[tid] = p.b ? bf2f(p.b[tid]) : 0.f;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
 
+    if (tid < MC_C) bl[tid] = (p.b ? bf2f(p.b[tid]) : 0.f) * p.gain;              // (v + b) * gain = fma(v, gain, b * gain)
     const float strength = (p.noise && p.strength) ? p.strength[0] : 1.f;
-    uint4 pre[MC_PRE];
-    float pre_s[8], pre_d = 1.f, pre_nz[2] = {0.f, 0.f};     // the tile's modulation piece, demodulation entry and noise samples
-    auto fetch = [&](int tile) {
-        const int n = tile / (p.tiles_x * p.tiles_y), rem = tile - n * (p.tiles_x * p.tiles_y);
-        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const float clampv = p.clamp >= 0.f ? p.clamp : __builtin_inff();
+
+    // a workgroup stays inside ONE sample (blockIdx.y): its weights are modulated once, before the loop
+    const int tiles_per_n = p.tiles_x * p.tiles_y;
+    const int n = blockIdx.y;
+    const int t_begin = blockIdx.x * p.per_wg;
+    const int t_end = t_begin + p.per_wg < tiles_per_n ? t_begin + p.per_wg : tiles_per_n;
+    if (t_begin >= t_end) return;
+
+    // ---- halo of tile `t` -> LDS buffer `buf`: this wave's pieces q = wave + 4 * i, i = 0..7, as LDS-DMA (one instruction each)
+    // (the per-lane parts of these offsets do not depend on the tile: left alone, the compiler keeps all of them -- and the 72
+    // fragment addresses of the multiplication -- in registers across the whole launch, and the 144 weight registers spill.
+    // An opaque copy of the lane id makes it recompute them: ~150 VALU instructions per tile in the shadow of 72 MFMAs.)
+    auto issue_piece = [&](int t, int buf, int i) {
+        const int q = wave + 4 * i;
+        if (q >= MC_PIECES) return;                                     // (wave-uniform)
+        const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
         const int y0 = ty * MC_TH - 1, x0 = tx * MC_TW - 1;
-        if (p.s) {
-            const float4 a = *(const float4*)(p.s + (size_t)n * MC_C + c8 * 8), b4 = *(const float4*)(p.s + (size_t)n * MC_C + c8 * 8 + 4);
-            pre_s[0] = a.x; pre_s[1] = a.y; pre_s[2] = a.z; pre_s[3] = a.w; pre_s[4] = b4.x; pre_s[5] = b4.y; pre_s[6] = b4.z; pre_s[7] = b4.w;
-        }
-        if (p.d && tid < MC_C) pre_d = p.d[(size_t)n * MC_C + tid];
-        if (p.noise && p.y) {
-            #pragma unroll
-            for (int mi = 0; mi < 2; mi++)
-                pre_nz[mi] = p.noise[(size_t)n * p.noise_stride_n + (size_t)(ty * MC_TH + wave * 2 + mi) * p.w_ + tx * MC_TW + r];
-        }
+        uint32_t lv = (uint32_t)lane;
+        asm volatile("" : "+v"(lv));
+        const int hy = q / 5;
+        const uint32_t pair = (uint32_t)(q - hy * 5) * 4u + (lv >> 4);      // pixel pair inside the halo row
+        const uint32_t l = (lv & 15u) ^ (pair & 15u);
+        const int hx = (int)(pair * 2u + (l >> 3));
+        const int gy = y0 + hy, gx = x0 + hx;
+        const int ok = (hx < MC_TW + 2) & ((uint32_t)gy < (uint32_t)p.h) & ((uint32_t)gx < (uint32_t)p.w_);      // (one select, no branches)
+        // out-of-image (and unused) slots: an offset beyond the buffer -> the range check returns zeros
+        const uint32_t off = ok ? ((uint32_t)((n * p.h + gy) * p.w_ + gx) * 128u + (l & 7u) * 16u) : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(halo + buf * MC_HALO_BYTES + q * 1024),
+                                                 16, (int)off, 0, 0, 0);
+    };
+    auto issue_halo = [&](int t, int buf) {
         #pragma unroll
-        for (int i = 0; i < MC_PRE; i++) {
-            const int chunk = tid + i * 256, pix = chunk >> 3;
-            const int py = pix / MC_HW, px = pix - py * MC_HW;
-            const int gy = y0 + py, gx = x0 + px;
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (pix < MC_HH * MC_HW && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_)
-                v = *(const uint4*)(p.x + (((size_t)n * p.h + gy) * p.w_ + gx) * MC_C + c8 * 8);
-            pre[i] = v;
-        }
+        for (int i = 0; i < (MC_PIECES + 3) / 4; i++) issue_piece(t, buf, i);
     };
 
-    unsigned long long t_[6] = {0, 0, 0, 0, 0, 0}, tc = 0;
-    #define MC_MARK(i) do { if (p.timing) { unsigned long long now = __builtin_readcyclecounter(); t_[i] += now - tc; tc = now; } } while (0)
-    int tile = blockIdx.x;
-    if (tile < p.tiles) fetch(tile);
-    if (p.timing) tc = __builtin_readcyclecounter();
-    for (; tile < p.tiles; tile += gridDim.x) {
-        const int n = tile / (p.tiles_x * p.tiles_y), rem = tile - n * (p.tiles_x * p.tiles_y);
-        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        const int oy0 = ty * MC_TH, ox0 = tx * MC_TW;
-
-        // ---- halo (already in registers) -> LDS, modulated
-        float sv[8];
-        #pragma unroll
-        for (int j = 0; j < 8; j++) sv[j] = p.s ? bf2f(from_acc<mg_bf16>(pre_s[j])) : 1.f;
-        const float nzv[2] = {pre_nz[0], pre_nz[1]};
-        #pragma unroll
-        for (int i = 0; i < MC_PRE; i++) {
-            const int chunk = tid + i * 256, pix = chunk >> 3;
-            if (pix < MC_HH * MC_HW) {
-                Pack8 v; v.u = pre[i];
-                if (p.s) {
-                    #pragma unroll
-                    for (int j = 0; j < 8; j++) v.h[j] = from_acc<mg_bf16>(bf2f(v.h[j]) * sv[j]);
-                }
-                *(uint4*)(al + (size_t)pix * MC_ROW + c8 * 8) = v.u;
-                if (p.xs) {         // the tile's own pixels (not the halo ring) of the modulated input, for the backward pass
-                    const int py = pix / MC_HW, px = pix - py * MC_HW;
-                    if (py >= 1 && py <= MC_TH && px >= 1 && px <= MC_TW)
-                        *(uint4*)(p.xs + (((size_t)n * p.h + oy0 + py - 1) * p.w_ + ox0 + px - 1) * MC_C + c8 * 8) = v.u;
-                }
-            }
-        }
-        if (tid < MC_C) dl[tid] = p.d ? pre_d : 1.f;
-        __syncthreads();
-        MC_MARK(0);
-
-        // ---- next tile's halo goes into flight now; it lands while the matrix cores work
-        if (tile + (int)gridDim.x < p.tiles) fetch(tile + gridDim.x);
-
-        MC_MARK(1);
-        // ---- 9 taps x 4 k-steps x (2 channel halves x 2 rows) MFMAs
-        f32x16 acc[2][2];
-        #pragma unroll
-        for (int a = 0; a < 2; a++)
-            #pragma unroll
-            for (int b2 = 0; b2 < 2; b2++)
-                #pragma unroll
-                for (int e = 0; e < 16; e++) acc[a][b2][e] = 0.f;
-        #pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            const int kh = tap / 3, kw = tap - kh * 3;
-            const mg_bf16* wrow = wl + ((size_t)tap * MC_C + r) * MC_ROW + hh * 8;                 // + ni * 32 * MC_ROW + kc * 16
-            const mg_bf16* arow = al + ((size_t)(wave * 2 + kh) * MC_HW + r + kw) * MC_ROW + hh * 8;  // + mi * MC_HW * MC_ROW + kc * 16
+    // ---- this wave's 36 weight fragments: A[row = co][k = 8*hh + j] = w[ob*32 + r][tap][kc*16 + 8*hh + j] (* s[n][ci], rounded)
+    bf16x8 wreg[9][4];
+    {
+        float sv[4][8];
+        if (MOD) {
             #pragma unroll
             for (int kc = 0; kc < 4; kc++) {
-                bf16x8 wf[2], xf[2];
-                #pragma unroll
-                for (int ni = 0; ni < 2; ni++) wf[ni] = *(const bf16x8*)(wrow + (size_t)ni * 32 * MC_ROW + kc * 16);
-                #pragma unroll
-                for (int mi = 0; mi < 2; mi++) xf[mi] = *(const bf16x8*)(arow + (size_t)mi * MC_HW * MC_ROW + kc * 16);
-                #pragma unroll
-                for (int ni = 0; ni < 2; ni++)
-                    #pragma unroll
-                    for (int mi = 0; mi < 2; mi++)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+                const f4_t a = *(const f4_t*)(p.s + (size_t)n * MC_C + kc * 16 + hh * 8), b4 = *(const f4_t*)(p.s + (size_t)n * MC_C + kc * 16 + hh * 8 + 4);
+                sv[kc][0] = rbf(a.x); sv[kc][1] = rbf(a.y); sv[kc][2] = rbf(a.z); sv[kc][3] = rbf(a.w);
+                sv[kc][4] = rbf(b4.x); sv[kc][5] = rbf(b4.y); sv[kc][6] = rbf(b4.z); sv[kc][7] = rbf(b4.w);
             }
         }
-        __syncthreads();            // every wave is done reading the halo tile: its LDS becomes the output staging area
+        #pragma unroll
+        for (int tap = 0; tap < 9; tap++)
+            #pragma unroll
+            for (int kc = 0; kc < 4; kc++) {
+                bf16x8 v = *(const bf16x8*)(p.w + ((size_t)(ob * 32 + r) * 9 + tap) * MC_C + kc * 16 + hh * 8);
+                if (MOD) {
+                    #pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = (__bf16)((float)v[j] * sv[kc][j]);
+                }
+                wreg[tap][kc] = v;
+            }
+    }
+    issue_halo(t_begin, 0);
+    // per-sample constants of the epilogue: the workgroup stays inside sample n
+    if (tid < MC_C) dl[tid] = p.d ? rbf(p.d[(size_t)n * MC_C + tid]) : 1.f;     // dcoefs.to(x.dtype)
+    float nz_next[2] = {0.f, 0.f};
+    if (p.noise && p.y) {
+        const int ty0 = t_begin / p.tiles_x, tx0 = t_begin - ty0 * p.tiles_x;
+        #pragma unroll
+        for (int pb = 0; pb < 2; pb++)
+            nz_next[pb] = p.noise[(size_t)n * p.noise_stride_n + (size_t)(ty0 * MC_TH + rh * 2 + pb) * p.w_ + tx0 * MC_TW + r];
+    }
+
+    unsigned long long tm[5] = {0, 0, 0, 0, 0}, tc = 0;
+#define MC_MARK(i) do { if (DBG) { unsigned long long now = __builtin_readcyclecounter(); tm[i] += now - tc; tc = now; } } while (0)
+    if (DBG) tc = __builtin_readcyclecounter();
+    for (int t = t_begin; t < t_end; t++) {
+        const int buf = (t - t_begin) & 1;
+        const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+        const int oy0 = ty * MC_TH, ox0 = tx * MC_TW;
+
+        MC_MARK(0);
+        __syncthreads();                // halo(t) has landed (vmcnt(0) + barrier); every wave is done with buffer buf^1
+        MC_MARK(1);
+        // the noise samples of the NEXT tile go into flight now (its halo follows, spread over the first MFMAs)
+        float nzv[2] = {nz_next[0], nz_next[1]};
+        if (t + 1 < t_end) {
+            if (p.noise && p.y) {
+                const int ty1 = (t + 1) / p.tiles_x, tx1 = (t + 1) - ty1 * p.tiles_x;
+                #pragma unroll
+                for (int pb = 0; pb < 2; pb++)
+                    nz_next[pb] = p.noise[(size_t)n * p.noise_stride_n + (size_t)(ty1 * MC_TH + rh * 2 + pb) * p.w_ + tx1 * MC_TW + r];
+            }
+        }
         MC_MARK(2);
 
-        // ---- outputs.  acc[ni][mi][reg]: output channel ni*32 + (reg&3) + 8*(reg>>2) + 4*hh of pixel (row wave*2+mi, column r)
-        const BaConst<float> k = {p.alpha, p.gain, p.clamp};
-        // this lane's 32 output channels: demodulation (rounded to the activation dtype, the reference's `dcoefs.to(x.dtype)`)
-        // and bias, fetched from LDS once per tile as 16-byte reads -- not once per element inside the loops below, where
-        // every read would be a full LDS round trip in front of its arithmetic at one wave per SIMD
-        float dq[2][4][4], bq[2][4][4];
+        // ---- per pixel row of the wave: 9 taps x 4 k-steps into ONE accumulator tile (16 registers), then its epilogue; the 2
+        // fragment reads of half-tap g + 1 are issued before the 2 MFMAs of half-tap g
+        const LDS_ unsigned char* hb = (const LDS_ unsigned char*)(halo + buf * MC_HALO_BYTES);
+        unsigned char* const st = stage + wave * MC_STAGE_BYTES;
         #pragma unroll
-        for (int ni = 0; ni < 2; ni++)
+        for (int pb = 0; pb < 2; pb++) {
+            uint32_t lv = (uint32_t)lane;
+            asm volatile("" : "+v"(lv));                                // see issue_piece
+            const uint32_t rv = lv & 31u, hv = lv >> 5;
+            // the lane's three column addresses (kw = 0, 1, 2) at k-step 0; k-step kc is an XOR of bits 5..6, the row an immediate
+            uint32_t col[3];
             #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int co = ni * 32 + 8 * g + 4 * hh;
-                const float4 dv = *(const float4*)(dl + co), bv = *(const float4*)(bl + co);
-                dq[ni][g][0] = bf2f(from_acc<mg_bf16>(dv.x)); dq[ni][g][1] = bf2f(from_acc<mg_bf16>(dv.y));
-                dq[ni][g][2] = bf2f(from_acc<mg_bf16>(dv.z)); dq[ni][g][3] = bf2f(from_acc<mg_bf16>(dv.w));
-                bq[ni][g][0] = bv.x; bq[ni][g][1] = bv.y; bq[ni][g][2] = bv.z; bq[ni][g][3] = bv.w;
-            }
-        for (int which = 0; which < 2; which++) {
-            mg_bf16* out = which == 0 ? p.yconv : p.y;
-            if (!out) continue;
+            for (int kw = 0; kw < 3; kw++) col[kw] = mc_col_off(rv + (uint32_t)kw, hv);
+            f32x16 acc;
             #pragma unroll
-            for (int mi = 0; mi < 2; mi++) {
-                const int prow = wave * 2 + mi;
-                const float nz = nzv[mi];
+            for (int e = 0; e < 16; e++) acc[e] = 0.f;
+            bf16x8 frag[2][2];
+            auto read_half = [&](int g, bf16x8 (&f)[2]) {               // g = tap * 2 + (k-steps 0,1 | 2,3)
+                const int tap = g >> 1, kh = tap / 3, kw = tap - kh * 3;
                 #pragma unroll
-                for (int ni = 0; ni < 2; ni++)
-                    #pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        const int co = ni * 32 + 8 * g + 4 * hh;
-                        union { uint2 u; mg_bf16 h[4]; } q;
-                        #pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            float v = bf2f(from_acc<mg_bf16>(acc[ni][mi][g * 4 + e]));      // the convolution's own bf16 result
-                            if (which == 1) {
-                                // the arithmetic of fma_bias_act_nhwc_fwd_kernel (csrc/fused.hip): d rounded to the activation
-                                // dtype, one fma for the noise, the sum rounded to the activation dtype, then bias + act + gain + clamp
-                                if (p.d) v *= dq[ni][g][e];
-                                if (p.noise) v = __builtin_fmaf(nz, strength, v);
-                                v = bf2f(from_acc<mg_bf16>(v));
-                                v = ba_eval<float, ACT>(0, v, bq[ni][g][e], 0.f, 0.f, 1.f, k);
-                            }
-                            q.h[e] = from_acc<mg_bf16>(v);
-                        }
-                        *(uint2*)(al + ((size_t)prow * MC_TW + r) * MC_ROW + co) = q.u;
-                    }
-            }
-            __syncthreads();
-            MC_MARK(3);
-            // 256 pixels x 8 pieces of 16 bytes, consecutive lanes on consecutive pieces of an NHWC row
+                for (int j = 0; j < 2; j++) {
+                    const uint32_t a = col[kw] ^ (uint32_t)(((g & 1) * 2 + j) << 5);       // (an XOR below bit 8 stays inside the 256-byte bank row)
+                    f[j] = *(const LDS_ bf16x8*)(hb + a + (rh * 2 + pb + kh) * (MC_HROW * 128));
+                }
+            };
+            read_half(0, frag[0]);
             #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int chunk = tid + i * 256, pix = chunk >> 3;
-                const int prow = pix >> 5, pcol = pix & 31;
-                const uint4 v = *(const uint4*)(al + (size_t)pix * MC_ROW + c8 * 8);
-                *(uint4*)(out + (((size_t)n * p.h + oy0 + prow) * p.w_ + ox0 + pcol) * MC_C + c8 * 8) = v;
+            for (int g = 0; g < 18; g++) {
+                if (g + 1 < 18) read_half(g + 1, frag[(g + 1) & 1]);
+                // the next tile's halo: one DMA piece per MFMA pair of the first pixel row, issued in their shadow
+                if (pb == 0 && g < (MC_PIECES + 3) / 4 && t + 1 < t_end) issue_piece(t + 1, buf ^ 1, g);
+                __builtin_amdgcn_sched_barrier(0);
+                #pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[g >> 1][(g & 1) * 2 + j], frag[g & 1][j], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();
-            MC_MARK(4);
+            if (pb == 1) MC_MARK(3);
+
+            // ---- outputs.  acc[reg]: output channel ob*32 + (reg&3) + 8*(reg>>2) + 4*hh of pixel (row rh*2 + pb, column r).
+            // Two values per instruction (v_pk_mul/fma_f32, v_cvt_pk_bf16_f32): the epilogue is VALU time the other workgroup's
+            // MFMAs have to share the SIMD with.
+            #pragma unroll
+            for (int which = 0; which < 2; which++) {
+                mg_bf16* out = which == 0 ? p.yconv : p.y;
+                if (!out) continue;
+                // (no run-time switches in here: absent operands are neutral values -- d = 1, noise = 0, clamp = +inf -- because inside
+                // the unrolled code hipcc turns a uniform `if` into computing both sides and a v_cndmask per value)
+                const f2_t nzs2 = {nzv[pb] * 1.f, nzv[pb] * 1.f}, st2 = {strength, strength}, g2 = {p.gain, p.gain}, al2 = {p.alpha, p.alpha};
+                #pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int co = ob * 32 + 8 * g + 4 * hh;
+                    f4_t dv = {1.f, 1.f, 1.f, 1.f}, bv = {0.f, 0.f, 0.f, 0.f};
+                    if (which == 1) { dv = *(const LDS_ f4_t*)(dl + co); bv = *(const LDS_ f4_t*)(bl + co); }
+                    uint2 q;
+                    #pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        f2_t v = {acc[g * 4 + 2 * j], acc[g * 4 + 2 * j + 1]};
+                        uint32_t packed = pk_bf16(v);                               // the convolution's own bf16 result
+                        if (which == 1) {
+                            v = unpk_bf16(packed);
+                            const f2_t d2 = {dv[2 * j], dv[2 * j + 1]}, b2 = {bv[2 * j], bv[2 * j + 1]};
+                            v = v * d2;
+                            v = __builtin_elementwise_fma(nzs2, st2, v);
+                            v = rbf2(v);                                            // the fma output is a bf16 tensor in the three-launch path
+                            v = __builtin_elementwise_fma(v, g2, b2);               // (v + b) * gain
+                            if (ACT == 3) {                                         // 0 <= alpha <= 1 (checked by the host): lrelu(t) = max(t, alpha * t)
+                                const f2_t m = v * al2;
+                                v.x = __builtin_fmaxf(v.x, m.x); v.y = __builtin_fmaxf(v.y, m.y);
+                            }
+                            // v_med3_f32: a NaN comes out as min3 = -clamp, as bias_act's comparison chain leaves it
+                            v.x = __builtin_amdgcn_fmed3f(v.x, -clampv, clampv);
+                            v.y = __builtin_amdgcn_fmed3f(v.y, -clampv, clampv);
+                            packed = pk_bf16(v);
+                        }
+                        if (j == 0) q.x = packed; else q.y = packed;
+                    }
+                    *(uint2*)(st + r * MC_STAGE_PX + g * 16 + hh * 8) = q;
+                }
+                // the wave's own strip: 32 pixels x 64 B, back as 16-byte pieces (lane -> pixel lane/4 (+16), piece lane%4)
+                #pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int px = (lane >> 2) + half * 16, piece = lane & 3;
+                    const uint4 v = *(const uint4*)(st + px * MC_STAGE_PX + piece * 16);
+                    *(uint4*)((unsigned char*)out + ((size_t)((n * p.h + oy0 + rh * 2 + pb) * p.w_ + ox0 + px) * MC_C + ob * 32) * 2 + piece * 16) = v;
+                }
+            }
         }
+        MC_MARK(4);
     }
-    if (p.timing && blockIdx.x == 0 && tid == 0)
-        for (int i = 0; i < 5; i++) p.timing[i] = t_[i];
+    if (DBG && p.timing && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+        for (int i = 0; i < 5; i++) p.timing[i] = tm[i];
+#undef MC_MARK
 }
 
 } // namespace
@@ -253,30 +300,48 @@ extern "C" int mg_modconv3x3_c64(const void* x, const void* w, const float* s, c
                                  int act, float alpha, float gain, float clamp, void* stream)
 {
     MG_REQUIRE(x && w && (y || yconv), "modconv3x3_c64: null pointer");
+    MG_REQUIRE(!xs, "modconv3x3_c64: the modulated input is no longer an output (the modulation is folded into the weights)");
     MG_REQUIRE(n >= 0 && h >= MC_TH && wd >= MC_TW && h % MC_TH == 0 && wd % MC_TW == 0,
                "modconv3x3_c64: height must be a multiple of %d and width of %d", MC_TH, MC_TW);
     MG_REQUIRE(act == 1 || act == 3, "modconv3x3_c64: activation must be linear (1) or lrelu (3)");
-    MG_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)yconv) & 15) == 0, "modconv3x3_c64: pointers must be 16-byte aligned");
-    MG_REQUIRE((int64_t)n * h * wd * MC_C <= INT32_MAX, "x is too large");
+    MG_REQUIRE(act == 1 || (alpha >= 0.f && alpha <= 1.f), "modconv3x3_c64: leaky ReLU slope must lie in [0, 1]");
+    MG_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)yconv | (uintptr_t)s) & 15) == 0, "modconv3x3_c64: pointers must be 16-byte aligned");
+    MG_REQUIRE((int64_t)n * h * wd * MC_C * 2 < (int64_t)0xFFFFFFF0u, "modconv3x3_c64: x is too large");
     if (n == 0) return MG_OK;
     McArgs p;
     p.x = (const mg_bf16*)x; p.w = (const mg_bf16*)w; p.s = s; p.d = d; p.noise = noise; p.strength = strength; p.b = (const mg_bf16*)b;
-    p.yconv = (mg_bf16*)yconv; p.y = (mg_bf16*)y; p.xs = (mg_bf16*)xs; p.n = n; p.h = h; p.w_ = wd; p.noise_stride_n = noise_stride_n;
-    p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    p.yconv = (mg_bf16*)yconv; p.y = (mg_bf16*)y; p.n = n; p.h = h; p.w_ = wd; p.noise_stride_n = noise_stride_n;
+    p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     p.tiles_x = wd / MC_TW; p.tiles_y = h / MC_TH; p.tiles = n * p.tiles_x * p.tiles_y;
-    p.timing = g_mc_timing;
-    const size_t lds = (size_t)(MC_W_ELEMS + MC_A_ELEMS) * 2 + 2 * MC_C * sizeof(float);
+    p.x_bytes = (uint32_t)((int64_t)n * h * wd * MC_C * 2);
+    // two workgroups per CU (512 in all), each a contiguous run of tiles of one sample
+    const int tiles_per_n = p.tiles_x * p.tiles_y;
+    int per_n = (512 + n - 1) / n;
+    if (per_n > tiles_per_n) per_n = tiles_per_n;
+    p.per_wg = (tiles_per_n + per_n - 1) / per_n;
+    per_n = (tiles_per_n + p.per_wg - 1) / p.per_wg;
+    const dim3 grid(per_n, n);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_c64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)modconv3x3_c64_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_c64_kernel<1, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MC_LDS);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_c64_kernel<3, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MC_LDS);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_c64_kernel<1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MC_LDS);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_c64_kernel<3, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MC_LDS);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_c64_kernel<3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MC_LDS);
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    const int grid = p.tiles < 256 ? p.tiles : 256;
     const double px = (double)n * h * wd * MC_C * 2;
-    MgLaunchScope scope(MG_K_MODCONV, st, px * (1 + (y ? 1 : 0) + (yconv ? 1 : 0) + (xs ? 1 : 0)) + 9.0 * MC_C * MC_C * 2);
-    if (act == 3) hipLaunchKernelGGL(modconv3x3_c64_kernel<3>, dim3(grid), dim3(256), lds, st, p);
-    else          hipLaunchKernelGGL(modconv3x3_c64_kernel<1>, dim3(grid), dim3(256), lds, st, p);
+    MgLaunchScope scope(MG_K_MODCONV, st, px * (1 + (y ? 1 : 0) + (yconv ? 1 : 0)) + 9.0 * MC_C * MC_C * 2);
+    p.timing = g_mc_timing;
+    if (s && act == 3 && g_mc_timing) {     // diagnostic instantiation (tools/bench_modconv.py): cycle stamps around the phases
+        hipLaunchKernelGGL((modconv3x3_c64_kernel<3, true, true>), grid, dim3(256), MC_LDS, st, p);
+    } else if (s) {
+        if (act == 3) hipLaunchKernelGGL((modconv3x3_c64_kernel<3, true, false>), grid, dim3(256), MC_LDS, st, p);
+        else          hipLaunchKernelGGL((modconv3x3_c64_kernel<1, true, false>), grid, dim3(256), MC_LDS, st, p);
+    } else {
+        if (act == 3) hipLaunchKernelGGL((modconv3x3_c64_kernel<3, false, false>), grid, dim3(256), MC_LDS, st, p);
+        else          hipLaunchKernelGGL((modconv3x3_c64_kernel<1, false, false>), grid, dim3(256), MC_LDS, st, p);
+    }
     return mg_check_launch(MG_K_MODCONV, "modconv3x3_c64");
 }

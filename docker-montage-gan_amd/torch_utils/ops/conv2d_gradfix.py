@@ -108,6 +108,11 @@ def _timed_call(input, weight_shape, n_products, kind):
 data_gradient_as_forward = True
 
 
+def _modconv3x3():
+    from . import modconv3x3        # (imports this module)
+    return modconv3x3
+
+
 def _lowp_nhwc(t):
     return t.is_cuda and t.dtype in (torch.bfloat16, torch.float16) and t.dim() == 4 and t.stride(1) == 1 and t.shape[1] > 1
 
@@ -180,6 +185,8 @@ def _conv2d_gradfix_build(transpose, weight_shape, stride, padding, output_paddi
     square3x3s1 = (not transpose and stride == (1, 1) and dilation == (1, 1) and groups == 1 and weight_shape[2:] == (3, 3)
                    and weight_shape[0] == weight_shape[1] >= 128 and max(padding) <= 2)
 
+    c64_3x3s1 = (not transpose and stride == (1, 1) and dilation == (1, 1) and groups == 1 and weight_shape == (64, 64, 3, 3))
+
     class Conv2d(torch.autograd.Function):
         @staticmethod
         def forward(ctx, input, weight, bias):
@@ -211,6 +218,11 @@ def _conv2d_gradfix_build(transpose, weight_shape, stride, padding, output_paddi
                             # 0.8-1.05 PFLOP/s where the library's data-gradient solver reaches 0.5-0.7
                             wt = weight.flip([2, 3]).transpose(0, 1).contiguous(memory_format=torch.channels_last)
                             grad_input = torch.convolution(grad_output, wt, None, [1, 1], [2 - padding[0], 2 - padding[1]], [1, 1], False, [0, 0], 1)
+                        elif need_x and c64_3x3s1 and padding == (1, 1) and _modconv3x3().applicable(grad_output, weight):
+                            # 64 -> 64: the matrix-core kernel of ops/modconv3x3.py as a plain convolution of dy with the flipped,
+                            # transposed weights
+                            M = _modconv3x3()
+                            grad_input = M.conv3x3_c64(grad_output.contiguous(memory_format=torch.channels_last), M.flipped_transposed(weight))
                         elif need_x:
                             grad_input = torch.ops.aten.convolution_backward(*bwd_args, [True, False, False])[0]
                         if need_w:

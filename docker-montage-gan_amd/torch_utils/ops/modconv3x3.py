@@ -40,7 +40,7 @@ enabled = os.environ.get('MG_MODCONV', '0') == '1'
 def applicable(x, weight, up=1, down=1):
     """True where the kernel's scope covers the call (GPU, bf16, channels-last, 64 -> 64, 3x3, no resampling, tile-aligned)."""
     return (enabled and x.is_cuda and x.dtype == torch.bfloat16 and x.ndim == 4 and up == 1 and down == 1
-            and tuple(weight.shape) == (64, 64, 3, 3) and x.shape[1] == 64 and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0
+            and tuple(weight.shape) == (64, 64, 3, 3) and x.shape[1] == 64 and x.shape[2] % 4 == 0 and x.shape[3] % 32 == 0
             and x.shape[0] > 0 and _me._is_nhwc(x))
 
 
@@ -54,6 +54,24 @@ def _launch(x, w, s32, d32, nz32, nz_stride, strength32, b16, want_conv, want_xs
             native.ptr(x), native.ptr(w), native.ptr(s32), native.ptr(d32), native.ptr(nz32), native.ptr(strength32), native.ptr(b16),
             native.ptr(yconv), native.ptr(y), native.ptr(xs), n, h, wd, nz_stride, act_idx, alpha, gain, clamp, native.stream_ptr(x.device)))
     return y, yconv, xs
+
+
+def conv3x3_c64(x, w):
+    """Plain 3x3 convolution (stride 1, padding 1, 64 -> 64, bf16 channels-last) through the same kernel, no autograd: what the
+    data gradient of these layers is -- ``conv3x3_c64(dy, flipped_transposed(w))`` (the layer's own forward problem, as
+    conv2d_gradfix does for the wider layers through the library's forward solvers)."""
+    n, c, h, wd = x.shape
+    y = torch.empty_like(x)
+    with native.guard(x.device):
+        native.check(native.lib().mg_modconv3x3_c64(
+            native.ptr(x), native.ptr(w), None, None, None, None, None, None, native.ptr(y), None, n, h, wd, 0, 1, 0.0, 1.0, -1.0,
+            native.stream_ptr(x.device)))
+    return y
+
+
+def flipped_transposed(w):
+    """[O,I,3,3] -> the weights of the transposed problem: w'[i,o,kh,kw] = w[o,i,2-kh,2-kw], channels-last."""
+    return w.flip([2, 3]).transpose(0, 1).contiguous(memory_format=torch.channels_last)
 
 
 def _composition(x, w, styles, dcoefs, noise, strength, b, act, alpha, gain, clamp):
@@ -99,7 +117,7 @@ def _fused(act, alpha, gain, clamp):
             need_bwd = any(ctx.needs_input_grad)
             # the weight gradient of the convolution reads x * s: written by the same launch (one more store of the tile
             # while it is in registers) rather than recomputed in the backward pass (a read and a write)
-            want_xs = need_bwd and styles is not None and ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled
+            want_xs = False     # (round 3: the kernel folds the modulation into its weights; x * s is recomputed where the library's weight gradient needs it)
             want_conv = need_bwd and dcoefs is not None      # only the demodulation gradient reads the raw convolution output
             with conv2d_gradfix._timed_call(x, (64, 64, 3, 3), 1, 'fwd [mg_modconv3x3_c64]'):
                 y, yconv, xs = _launch(x, wc, s32, d32, nz32, nz_stride, st32, b16, want_conv, want_xs, idx, alpha, gain, clamp)
@@ -160,11 +178,11 @@ def _fused(act, alpha, gain, clamp):
                     xs = xs_saved if xs_saved.numel() else _me.channel_scale(x.detach(), styles.detach())
                 else:
                     xs = x.detach()
-                with conv2d_gradfix._timed_call(xs, (64, 64, 3, 3), int(bool(need_xs)) + int(need_w), 'bwd' + str(int(bool(need_xs)) + int(need_w))):
-                    dxs, dw, _ = torch.ops.aten.convolution_backward(dyc, xs, w.detach(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                                     [bool(need_xs), need_w, False])
-                if not need_w:
-                    dw = None
+                with conv2d_gradfix._timed_call(xs, (64, 64, 3, 3), int(bool(need_xs)) + int(need_w), 'bwd' + str(int(bool(need_xs)) + int(need_w)) + ' [dx: mg_modconv3x3_c64]'):
+                    # the data gradient is this layer's forward problem on dy and the flipped, transposed weights: the same kernel
+                    dxs = conv3x3_c64(dyc, flipped_transposed(w.detach())) if need_xs else None
+                    dw = torch.ops.aten.convolution_backward(dyc, xs, w.detach(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                             [False, True, False])[1] if need_w else None
                 # (3) modulation: dx = dxs * s, ds = sum_hw dxs * x, one pass
                 if need_xs and has_s:
                     dx = torch.empty_like(x)

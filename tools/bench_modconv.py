@@ -80,7 +80,8 @@ if hasattr(L, 'mg_modconv_debug_timing'):
                 M.fused_modconv3x3(x, w, s, d, nz, st, b, act='lrelu', gain=gain, clamp=256)
         torch.cuda.synchronize()
         t = buf.cpu().tolist()
-        tiles = N * 256 // 1
-        per = [v / (N * 256 * 256 // 256 / 256) for v in t[:5]]
-        print(f'{label}: cycles per tile (workgroup 0): stage->LDS {per[0]:.0f}, issue prefetch {per[1]:.0f}, MFMA loop {per[2]:.0f}, epilogue {per[3]:.0f}, store {per[4]:.0f}; total {sum(per):.0f}')
+        tiles = (256 // 4) * (256 // 32) // max(1, (512 + N - 1) // N)          # tiles of workgroup (0, 0): one sample's tiles over its workgroups
+        per = [v / max(tiles, 1) for v in t[:5]]
+        print(f'{label}: cycles per tile (wave 0 of workgroup 0, {tiles} tiles): tile scalars {per[0]:.0f}, wait for the halo + barrier {per[1]:.0f}, '
+              f'issue next halo {per[2]:.0f}, MFMA loop {per[3]:.0f}, epilogue + stores {per[4]:.0f}; total {sum(per):.0f}')
     L.mg_modconv_debug_timing(None)
