@@ -428,6 +428,10 @@ template <class T> struct BnArgs {
     float alpha, gain, clamp;
     int64_t noise_stride_n;
     uint32_t c, hw, cv, slices, slice_pix;
+    // `recon`: the epilogue's input x is not read but rebuilt from its saved output y (what gd sums over):
+    //     pre = y / gain  (/ alpha where negative, lrelu),   x = (pre - noise * strength - b) / d
+    // exact up to the rounding of y to T; where the clamp saturated the gradient is zero and x does not matter.
+    const T* bias; const float* strength; int recon;
 };
 
 // One workgroup = one slice of the pixels of one sample.  256 % cv == 0, so a lane keeps the same channel vector
@@ -457,6 +461,20 @@ __global__ void __launch_bounds__(256) bwd_fused_nhwc_kernel(BnArgs<T> p)
     float s_gd[VEC], s_gb[VEC], s_gs = 0.f;
     #pragma unroll
     for (int e = 0; e < VEC; e++) { s_gd[e] = 0.f; s_gb[e] = 0.f; }
+    float bv[VEC], rdv[VEC];                // recon: bias and 1 / d of the lane's channels
+    #pragma unroll
+    for (int e = 0; e < VEC; e++) { bv[e] = 0.f; rdv[e] = 1.f; }
+    const float rstr = (p.recon && p.strength) ? *p.strength : 1.f;
+    const float rgain = 1.f / p.gain, ralpha = (A == 3 && p.alpha != 0.f) ? 1.f / p.alpha : 0.f;
+    if (p.recon) {
+        if (p.bias) {
+            const V b16 = *(const V*)(p.bias + cvi * VEC);
+            #pragma unroll
+            for (int e = 0; e < VEC; e++) bv[e] = to_acc<T>(b16.v[e]);
+        }
+        #pragma unroll
+        for (int e = 0; e < VEC; e++) rdv[e] = 1.f / dv[e];
+    }
     constexpr int BU = 4;
     for (uint32_t pix0 = lo + pl; pix0 < hi; pix0 += ppi * BU) {
         V vdy[BU], vy[BU], vx[BU];
@@ -485,6 +503,11 @@ __global__ void __launch_bounds__(256) bwd_fused_nhwc_kernel(BnArgs<T> p)
                 out.v[e] = from_acc<T>(gq * dv[e]);
                 s_gb[e] += gq;
                 if (p.x) s_gd[e] += gq * to_acc<T>(vx[u].v[e]);
+                else if (p.recon) {
+                    float pre = to_acc<T>(vy[u].v[e]) * rgain;
+                    if (A == 3 && pre < 0.f) pre *= ralpha;
+                    s_gd[e] += gq * ((pre - nz[u] * rstr - bv[e]) * rdv[e]);
+                }
                 srow += gq;
             }
             if (nzp) s_gs += srow * nz[u];
@@ -683,14 +706,27 @@ extern "C" int mg_bwd_fused_nhwc(const void* dy, const void* yref, const void* x
     MG_REQUIRE(dy && dx, "dy must reside on the device");
     MG_REQUIRE(dtype == MG_F32 || dtype == MG_F16 || dtype == MG_BF16, "bwd_fused_nhwc: unsupported dtype %d", dtype);
     MG_REQUIRE(n >= 0 && c >= 1 && hw >= 1, "bwd_fused_nhwc: bad shape");
-    MG_REQUIRE(!gd || x, "bwd_fused_nhwc: gd needs x");
+    return mg_bwd_fused_nhwc_y(dy, yref, x, d, noise, nullptr, nullptr, 0, dx, gd, gb_partial, gs, dtype, act, alpha, gain, clamp,
+                               noise_stride_n, n, c, hw, stream);
+}
+
+extern "C" int mg_bwd_fused_nhwc_y(const void* dy, const void* yref, const void* x, const float* d, const float* noise,
+                                   const float* strength, const void* bias, int recon, void* dx, float* gd, float* gb_partial, float* gs,
+                                   int dtype, int act, float alpha, float gain, float clamp, int64_t noise_stride_n, int32_t n, int32_t c,
+                                   int32_t hw, void* stream)
+{
+    MG_REQUIRE(dy && dx, "dy must reside on the device");
+    MG_REQUIRE(dtype == MG_F32 || dtype == MG_F16 || dtype == MG_BF16, "bwd_fused_nhwc: unsupported dtype %d", dtype);
+    MG_REQUIRE(n >= 0 && c >= 1 && hw >= 1, "bwd_fused_nhwc: bad shape");
+    MG_REQUIRE(!gd || x || recon, "bwd_fused_nhwc: gd needs x (or recon)");
+    MG_REQUIRE(!recon || (yref && !x && gain != 0.f && (act == 1 || act == 3)), "bwd_fused_nhwc: recon needs the saved output, a non-zero gain and a linear / lrelu activation");
     MG_REQUIRE(!gs || noise, "bwd_fused_nhwc: gs needs noise");
     int64_t total = (int64_t)n * c * hw;
     MG_REQUIRE(total <= INT32_MAX, "x is too large");
     if (total == 0) return MG_OK;
     int es = mg_dtype_size(dtype), vec = 16 / es;
     MG_REQUIRE(c % vec == 0 && c / vec <= 256 && 256 % (c / vec) == 0, "bwd_fused_nhwc: channels/%d must divide 256", vec);
-    MG_REQUIRE((((uintptr_t)dy | (uintptr_t)yref | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)d) & 15) == 0, "bwd_fused_nhwc: pointers must be 16-byte aligned");
+    MG_REQUIRE((((uintptr_t)dy | (uintptr_t)yref | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)d | (uintptr_t)bias) & 15) == 0, "bwd_fused_nhwc: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     int passes = 2 + (yref != nullptr) + (x != nullptr);
     MgLaunchScope scope(MG_K_BWD_FUSED, s, (double)passes * total * es);
@@ -698,8 +734,9 @@ extern "C" int mg_bwd_fused_nhwc(const void* dy, const void* yref, const void* x
     MG_DISPATCH_DTYPE(dtype, {
         if (sizeof(T) == 8) break;
         BnArgs<T> p;
-        p.dy = (const T*)dy; p.yref = (const T*)yref; p.x = (const T*)x; p.d = d; p.noise = gs ? noise : nullptr; p.dx = (T*)dx;
+        p.dy = (const T*)dy; p.yref = (const T*)yref; p.x = (const T*)x; p.d = d; p.noise = (gs || (recon && gd)) ? noise : nullptr; p.dx = (T*)dx;
         p.gd = gd; p.gb = gb_partial; p.gs = gs; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.noise_stride_n = noise_stride_n;
+        p.bias = (const T*)bias; p.strength = strength; p.recon = (recon && gd) ? 1 : 0;
         p.c = (uint32_t)c; p.hw = (uint32_t)hw; p.cv = (uint32_t)(c / vec);
         const uint32_t ppi = 256u / p.cv, unit = ppi * 4u;            // pixels per round of 4 vectors in flight
         uint32_t per = unit * 4u;                                     // about 16 vectors per lane per slice

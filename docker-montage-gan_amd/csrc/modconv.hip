@@ -43,6 +43,8 @@ constexpr int MC_HR = MC_TH + 2;                    // halo rows
 constexpr int MC_HROW = 40;                         // pixels per halo row in LDS (34 used; 5 DMA pieces of 8 pixels)
 constexpr int MC_PIECES = MC_HR * MC_HROW / 8;      // 30 pieces of 1 KiB
 constexpr int MC_HALO_BYTES = MC_PIECES * 1024;     // 30,720
+constexpr int MC_STAGGER = 1;                       // s_sleep(64) repeats for the workgroup in the odd wave slot (~4k cycles)
+constexpr int MC_RING = 5;                          // fragment reads in flight per wave (+1)
 constexpr int MC_STAGE_PX = 80;                     // bytes per pixel of the output staging strip (64 + 16: 16-byte aligned, 2-way on the 8-byte writes)
 constexpr int MC_STAGE_BYTES = 32 * MC_STAGE_PX;    // one 32-pixel block x 32 channels per wave
 constexpr int MC_LDS = 2 * MC_HALO_BYTES + 4 * MC_STAGE_BYTES + 2 * MC_C * 4;      // + d + bias
@@ -172,6 +174,16 @@ __global__ void __launch_bounds__(256, 2) modconv3x3_c64_kernel(McArgs p)
             nz_next[pb] = p.noise[(size_t)n * p.noise_stride_n + (size_t)(ty0 * MC_TH + rh * 2 + pb) * p.w_ + tx0 * MC_TW + r];
     }
 
+    // Two workgroups share a CU and run the same program: left alone they march in step -- both in their multiplication (each
+    // wave gets every other slot of its SIMD's matrix pipe: 75 cycles per MFMA measured), then both in their epilogue (pipe idle).
+    // The workgroup in the odd wave slot therefore starts half a tile late, once; after that its epilogues fall into the other's
+    // multiplications.  (Which workgroups share a CU is the dispatcher's business: the wave slot id is read from the hardware.)
+    if (MC_STAGGER) {
+        const uint32_t hw_id = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));     // HW_REG_HW_ID, bits 3:0 = wave slot on the SIMD
+        if (hw_id & 1u)
+            for (int i = 0; i < MC_STAGGER; i++) __builtin_amdgcn_s_sleep(64);                  // 64 x 64 cycles each
+    }
+
     unsigned long long tm[5] = {0, 0, 0, 0, 0}, tc = 0;
 #define MC_MARK(i) do { if (DBG) { unsigned long long now = __builtin_readcyclecounter(); tm[i] += now - tc; tc = now; } } while (0)
     if (DBG) tc = __builtin_readcyclecounter();
@@ -195,8 +207,7 @@ __global__ void __launch_bounds__(256, 2) modconv3x3_c64_kernel(McArgs p)
         }
         MC_MARK(2);
 
-        // ---- per pixel row of the wave: 9 taps x 4 k-steps into ONE accumulator tile (16 registers), then its epilogue; the 2
-        // fragment reads of half-tap g + 1 are issued before the 2 MFMAs of half-tap g
+        // ---- per pixel row of the wave: 9 taps x 4 k-steps into ONE accumulator tile (16 registers), then its epilogue
         const LDS_ unsigned char* hb = (const LDS_ unsigned char*)(halo + buf * MC_HALO_BYTES);
         unsigned char* const st = stage + wave * MC_STAGE_BYTES;
         #pragma unroll
@@ -211,25 +222,23 @@ __global__ void __launch_bounds__(256, 2) modconv3x3_c64_kernel(McArgs p)
             f32x16 acc;
             #pragma unroll
             for (int e = 0; e < 16; e++) acc[e] = 0.f;
-            bf16x8 frag[2][2];
-            auto read_half = [&](int g, bf16x8 (&f)[2]) {               // g = tap * 2 + (k-steps 0,1 | 2,3)
-                const int tap = g >> 1, kh = tap / 3, kw = tap - kh * 3;
-                #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const uint32_t a = col[kw] ^ (uint32_t)(((g & 1) * 2 + j) << 5);       // (an XOR below bit 8 stays inside the 256-byte bank row)
-                    f[j] = *(const LDS_ bf16x8*)(hb + a + (rh * 2 + pb + kh) * (MC_HROW * 128));
-                }
+            // a ring of MC_RING fragments: the read of k-step i + MC_RING - 1 is issued before the MFMA of k-step i, i.e. four MFMAs
+            // (128 cycles) ahead of its use -- with 144 VGPRs of weights there is no room for more, and LDS latency under load is above 100
+            bf16x8 frag[MC_RING];
+            auto read_step = [&](int i, bf16x8& f) {                    // i = tap * 4 + kc
+                const int tap = i >> 2, kh = tap / 3, kw = tap - kh * 3;
+                const uint32_t a = col[kw] ^ (uint32_t)((i & 3) << 5);  // (an XOR below bit 8 stays inside the 256-byte bank row)
+                f = *(const LDS_ bf16x8*)(hb + a + (rh * 2 + pb + kh) * (MC_HROW * 128));
             };
-            read_half(0, frag[0]);
             #pragma unroll
-            for (int g = 0; g < 18; g++) {
-                if (g + 1 < 18) read_half(g + 1, frag[(g + 1) & 1]);
-                // the next tile's halo: one DMA piece per MFMA pair of the first pixel row, issued in their shadow
-                if (pb == 0 && g < (MC_PIECES + 3) / 4 && t + 1 < t_end) issue_piece(t + 1, buf ^ 1, g);
+            for (int i = 0; i < MC_RING - 1; i++) read_step(i, frag[i]);
+            #pragma unroll
+            for (int i = 0; i < 36; i++) {
+                if (i + MC_RING - 1 < 36) read_step(i + MC_RING - 1, frag[(i + MC_RING - 1) % MC_RING]);
+                // the next tile's halo: one DMA piece per 2 MFMAs of the first pixel row, issued in their shadow
+                if (pb == 0 && (i & 1) == 0 && (i >> 1) < (MC_PIECES + 3) / 4 && t + 1 < t_end) issue_piece(t + 1, buf ^ 1, i >> 1);
                 __builtin_amdgcn_sched_barrier(0);
-                #pragma unroll
-                for (int j = 0; j < 2; j++)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[g >> 1][(g & 1) * 2 + j], frag[g & 1][j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[i >> 2][i & 3], frag[i % MC_RING], acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (pb == 1) MC_MARK(3);

@@ -22,6 +22,41 @@ struct UfParams {
     int upx, upy, downx, downy, padx0, pady0, flip; float gain;
     int n, c, in_h, in_w, out_h, out_w, f_h, f_w;
     int64_t xs_n, xs_c, xs_h, xs_w, ys_n, ys_c, ys_h, ys_w, fs_h, fs_w;
+    // mg_upfirdn2d_epilogue (channels-last 1:1 kernels): the modulated-convolution epilogue applied to the filter's output on its
+    // way out -- y = bias_act(fma(T(fir), T(d[n,c]), noise[n,oy,ox] * strength), b, act, gain, clamp), the arithmetic and rounding
+    // points of fma_bias_act_nhwc_fwd_kernel (csrc/fused.hip) on the T tensor the filter would have stored
+    const float* ep_d; const float* ep_noise; const float* ep_strength; const void* ep_b;
+    int64_t ep_noise_stride_n; float ep_alpha, ep_gain, ep_clamp;
+};
+
+#include "mg_act.h"
+
+// EPI = 0: none; 1 / 3: epilogue with the linear / leaky-ReLU activation
+template <class T, int EPI, int VEC> struct UfEpiLane {
+    float d[VEC], b[VEC], st;
+    __device__ __forceinline__ void init(const UfParams& p, uint32_t n, uint32_t cvi)
+    {
+        if (EPI == 0) return;
+        #pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            d[e] = p.ep_d ? (float)to_acc<T>(from_acc<T>(p.ep_d[(size_t)n * p.c + cvi * VEC + e])) : 1.f;
+            b[e] = p.ep_b ? (float)to_acc<T>(((const T*)p.ep_b)[cvi * VEC + e]) : 0.f;
+        }
+        st = (p.ep_noise && p.ep_strength) ? *p.ep_strength : 1.f;
+    }
+    // v: the filter's float32 result of one pixel's channel vector; nz: the pixel's noise sample
+    __device__ __forceinline__ void apply(const UfParams& p, float (&v)[VEC], float nz) const
+    {
+        if (EPI == 0) return;
+        const BaConst<float> k = {p.ep_alpha, p.ep_gain, p.ep_clamp};
+        #pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            float t = (float)to_acc<T>(from_acc<T>(v[e])) * d[e];           // the filter's output is a T tensor
+            if (p.ep_noise) t = __builtin_fmaf(nz, st, t);
+            t = (float)to_acc<T>(from_acc<T>(t));
+            v[e] = ba_eval<float, (EPI == 0 ? 1 : EPI)>(0, t, b[e], 0.f, 0.f, 1.f, k);
+        }
+    }
 };
 
 // Integer receptive field of one output coordinate along one axis
@@ -521,7 +556,7 @@ template <class T> __device__ __forceinline__ u32x4_t nhwc_pack2(const f2_t (&v)
 
 struct NhwcGrid { uint32_t cv, gx, nchunks, total, rows_per_chunk; FastDiv cv_div, gx_div, chunk_div; };
 
-template <class T, int UP, int DN, int PX, int PY, int MX, int MY>
+template <class T, int UP, int DN, int PX, int PY, int MX, int MY, int EPI = 0>
 __global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
 {
     constexpr int VEC = NhwcVec<T>::VEC, FW = 4, FH = 4, ES = (int)sizeof(T);
@@ -552,6 +587,8 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
     const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)in_bytes, 0x00020000);
     const auto rout = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)out_bytes, 0x00020000);
 
+    UfEpiLane<T, EPI, VEC> epi;
+    epi.init(p, n, cvi);
     const int pix_bytes = p.c * ES;
     const int ox0 = (int)gxi * MX;
     const int ix0 = mg_floor_div(UP - 1 - p.padx0, UP) + (int)gxi * LANE_DX;        // first input column of the lane window
@@ -632,7 +669,17 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
             #pragma unroll
             for (int i = 0; i < MX; i++) {
                 const unsigned off = (oy < p.out_h && st_off[i] != BAD) ? row_off + st_off[i] : BAD;
-                __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack2<T>(acc[j][i]), rout, off, 0, 0);
+                if (EPI) {
+                    float t[VEC];
+                    #pragma unroll
+                    for (int h = 0; h < VEC / 2; h++) { t[2 * h] = acc[j][i][h].x; t[2 * h + 1] = acc[j][i][h].y; }
+                    const bool in = oy < p.out_h && ox0 + i < p.out_w;
+                    const float nz = (p.ep_noise && in) ? p.ep_noise[(int64_t)n * p.ep_noise_stride_n + (int64_t)oy * p.out_w + ox0 + i] : 0.f;
+                    epi.apply(p, t, nz);
+                    __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack<T>(t), rout, off, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack2<T>(acc[j][i]), rout, off, 0, 0);
+                }
             }
         }
     }
@@ -643,7 +690,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
 // input row is loaded exactly once per chunk (the block kernel above re-reads the FH-1 rows two consecutive
 // blocks share, and those re-reads partly miss L2: 1.49x read traffic measured).  The next row is requested
 // before the current one is consumed.
-template <class T>
+template <class T, int EPI = 0>
 __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UfParams p, NhwcGrid g)
 {
     constexpr int VEC = NhwcVec<T>::VEC, FW = 4, FH = 4, ES = (int)sizeof(T);
@@ -671,6 +718,8 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UfParams p, NhwcGrid 
     const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)in_bytes, 0x00020000);
     const auto rout = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)out_bytes, 0x00020000);
 
+    UfEpiLane<T, EPI, VEC> epi;
+    epi.init(p, n, cvi);
     const int pix_bytes = p.c * ES;
     const int ox = (int)gxi, ix0 = ox - p.padx0;
     int col_off[FW];
@@ -725,7 +774,19 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UfParams p, NhwcGrid 
                 }
             }
             const int done = (r + 1) % FH;                                          // output row j - (FH-1) is complete
-            if (j >= FH - 1) __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack2<T>(acc[done]), rout, out_row_off + st_off, 0, 0);
+            if (j >= FH - 1) {
+                if (EPI) {
+                    float t[VEC];
+                    #pragma unroll
+                    for (int h = 0; h < VEC / 2; h++) { t[2 * h] = acc[done][h].x; t[2 * h + 1] = acc[done][h].y; }
+                    const int oy = oy_begin + j - (FH - 1);
+                    const float nz = p.ep_noise ? p.ep_noise[(int64_t)n * p.ep_noise_stride_n + (int64_t)oy * p.out_w + ox] : 0.f;
+                    epi.apply(p, t, nz);
+                    __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack<T>(t), rout, out_row_off + st_off, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack2<T>(acc[done]), rout, out_row_off + st_off, 0, 0);
+                }
+            }
             out_row_off += (unsigned)out_pitch;
             #pragma unroll
             for (int e = 0; e < VEC / 2; e++) acc[done][e] = (f2_t){0.f, 0.f};
@@ -734,6 +795,8 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UfParams p, NhwcGrid 
         }
     }
 }
+
+static thread_local int g_epi_act = 0;          // set by mg_upfirdn2d_epilogue around its launch (0: plain upfirdn2d)
 
 template <class T, int UP, int DN, int PX, int PY>
 void launch_nhwc_phase(const UfParams& p, hipStream_t s)
@@ -748,8 +811,17 @@ void launch_nhwc_phase(const UfParams& p, hipStream_t s)
     g.total = (uint32_t)p.n * g.nchunks * g.gx * g.cv;
     g.cv_div = make_fastdiv(g.cv); g.gx_div = make_fastdiv(g.gx); g.chunk_div = make_fastdiv(g.nchunks);
     // tall images: row streaming (every input row read once per chunk); short ones: the block kernel (more parallel slack)
-    if (UP == 1 && DN == 1 && p.out_h >= 192) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T>), dim3((g.total + 255u) / 256u), dim3(256), 0, s, p, g);
-    else hipLaunchKernelGGL((upfirdn2d_nhwc<T, UP, DN, PX, PY, MX, MY>), dim3((g.total + 255u) / 256u), dim3(256), 0, s, p, g);
+    const dim3 grid((g.total + 255u) / 256u);
+    if constexpr (UP == 1 && DN == 1 && sizeof(T) == 2) {
+        if (g_epi_act == 1 || g_epi_act == 3) {      // mg_upfirdn2d_epilogue: same kernels, epilogue on the way out
+            const bool rows = p.out_h >= 192;
+            if (g_epi_act == 3) { if (rows) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, 3>), grid, dim3(256), 0, s, p, g); else hipLaunchKernelGGL((upfirdn2d_nhwc<T, 1, 1, 0, 0, MX, MY, 3>), grid, dim3(256), 0, s, p, g); }
+            else                { if (rows) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, 1>), grid, dim3(256), 0, s, p, g); else hipLaunchKernelGGL((upfirdn2d_nhwc<T, 1, 1, 0, 0, MX, MY, 1>), grid, dim3(256), 0, s, p, g); }
+            return;
+        }
+    }
+    if (UP == 1 && DN == 1 && p.out_h >= 192) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T>), grid, dim3(256), 0, s, p, g);
+    else hipLaunchKernelGGL((upfirdn2d_nhwc<T, UP, DN, PX, PY, MX, MY>), grid, dim3(256), 0, s, p, g);
 }
 
 template <class T>
@@ -844,6 +916,7 @@ extern "C" int mg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
     p.xs_n = x_stride[0]; p.xs_c = x_stride[1]; p.xs_h = x_stride[2]; p.xs_w = x_stride[3];
     p.ys_n = y_stride[0]; p.ys_c = y_stride[1]; p.ys_h = y_stride[2]; p.ys_w = y_stride[3];
     p.fs_h = f_stride[0]; p.fs_w = f_stride[1];
+    p.ep_d = p.ep_noise = p.ep_strength = nullptr; p.ep_b = nullptr; p.ep_noise_stride_n = 0; p.ep_alpha = 0.f; p.ep_gain = 1.f; p.ep_clamp = -1.f;
     hipStream_t s = (hipStream_t)stream;
 
     bool tiled = false;
@@ -872,6 +945,40 @@ extern "C" int mg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
         else    hipLaunchKernelGGL((upfirdn2d_generic<T, false>), dim3(blocks), dim3(256), 0, s, p, total);
     });
     return mg_check_launch(MG_K_UPFIRDN2D_GENERIC, "upfirdn2d");
+}
+
+extern "C" int mg_upfirdn2d_epilogue(const void* x, const float* f, void* y, int dtype, const int32_t x_size[4], const int32_t f_size[2],
+                                     const int64_t f_stride[2], const int32_t y_size[4], int padx0, int pady0, int flip, float gain,
+                                     const float* d, const float* noise, const float* strength, const void* b, int64_t noise_stride_n,
+                                     int act, float alpha, float act_gain, float clamp, void* stream)
+{
+    MG_REQUIRE(x && f && y, "x must reside on the device");
+    MG_REQUIRE(dtype == MG_F16 || dtype == MG_BF16, "upfirdn2d_epilogue: float16 / bfloat16 channels-last tensors only");
+    MG_REQUIRE(act == 1 || act == 3, "upfirdn2d_epilogue: activation must be linear (1) or lrelu (3)");
+    MG_REQUIRE(f_size[0] >= 1 && f_size[1] >= 1 && f_size[0] <= 4 && f_size[1] <= 4, "upfirdn2d_epilogue: filters of at most 4x4 taps");
+    MG_REQUIRE(x_size[0] == y_size[0] && x_size[1] == y_size[1] && y_size[2] >= 1 && y_size[3] >= 1, "x and y must agree in batch and channels");
+    const int64_t C = x_size[1];
+    MG_REQUIRE(C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)b) & 15) == 0, "upfirdn2d_epilogue: channels must be a multiple of 8, pointers 16-byte aligned");
+    int64_t xn = (int64_t)x_size[0] * C * x_size[2] * x_size[3], yn = (int64_t)y_size[0] * C * y_size[2] * y_size[3];
+    const int64_t lim = (1ll << 31) - 64;
+    MG_REQUIRE(xn * 2 < lim && yn * 2 < lim && (int64_t)y_size[0] * ((y_size[2] + 31) / 32) * y_size[3] * (C / 8) < (int64_t)UINT32_MAX / 2, "x is too large");
+    if (yn == 0) return MG_OK;
+    UfParams p;
+    p.x = x; p.f = f; p.y = y;
+    p.upx = p.upy = p.downx = p.downy = 1; p.padx0 = padx0; p.pady0 = pady0; p.flip = flip ? 1 : 0; p.gain = gain;
+    p.n = x_size[0]; p.c = x_size[1]; p.in_h = x_size[2]; p.in_w = x_size[3];
+    p.out_h = y_size[2]; p.out_w = y_size[3]; p.f_h = f_size[0]; p.f_w = f_size[1];
+    p.xs_c = 1; p.xs_w = C; p.xs_h = C * p.in_w; p.xs_n = C * p.in_w * p.in_h;           // dense channels-last, checked by the caller
+    p.ys_c = 1; p.ys_w = C; p.ys_h = C * p.out_w; p.ys_n = C * p.out_w * p.out_h;
+    p.fs_h = f_stride[0]; p.fs_w = f_stride[1];
+    p.ep_d = d; p.ep_noise = noise; p.ep_strength = strength; p.ep_b = b; p.ep_noise_stride_n = noise_stride_n;
+    p.ep_alpha = alpha; p.ep_gain = act_gain; p.ep_clamp = clamp;
+    hipStream_t s = (hipStream_t)stream;
+    MgLaunchScope scope(MG_K_UPFIRDN2D_NHWC, s, (double)(xn + yn) * 2);
+    g_epi_act = act;
+    if (dtype == MG_BF16) launch_nhwc_phase<mg_bf16, 1, 1, 0, 0>(p, s); else launch_nhwc_phase<mg_half, 1, 1, 0, 0>(p, s);
+    g_epi_act = 0;
+    return mg_check_launch(MG_K_UPFIRDN2D_NHWC, "upfirdn2d_epilogue");
 }
 
 extern "C" int mg_upfirdn2d_index_table(int32_t* table, int out_size, int in_size, int up, int down, int pad0,

@@ -54,9 +54,11 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
 
 
 @misc.profiled_function
-def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False):
+def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False, tail=None):
     """x [N, C_in, H, W]; w [C_out, C_in/groups, kh, kw]; f from ``upfirdn2d.setup_filter`` or None;
-    padding is w.r.t. the up-sampled image and applied once, before everything else."""
+    padding is w.r.t. the up-sampled image and applied once, before everything else.
+    ``tail`` (additive, not in the reference's signature): a callable ``tail(x, f, padding, gain, flip_filter)`` that replaces the
+    blur ending the up-sampling path (up > 1, down == 1) -- SynthesisLayer passes the blur fused with its epilogue."""
     assert isinstance(x, torch.Tensor) and x.ndim == 4
     assert isinstance(w, torch.Tensor) and w.ndim == 4 and w.dtype == x.dtype
     assert f is None or (isinstance(f, torch.Tensor) and f.ndim in [1, 2] and f.dtype == torch.float32)
@@ -99,6 +101,8 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         pyt = max(min(-py0, -py1), 0)
         x = _conv2d_wrapper(x=x, w=wt, stride=up, padding=[pyt, pxt], groups=groups, transpose=True,
                             flip_weight=(not flip_weight))
+        if tail is not None and down == 1:
+            return tail(x, f, [px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt], up ** 2, flip_filter)
         x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt], gain=up ** 2,
                                 flip_filter=flip_filter)
         if down > 1:

@@ -5,21 +5,29 @@
 
     y = clamp(act(conv3x3(x * styles[N,Ci,1,1], w) * dcoefs[N,Co,1,1] + noise * noise_strength + b) * gain)
 
--- today three launches and six trips of the activation through HBM (modulation pass, library convolution, fused epilogue
-pass) -- in ONE launch of csrc/modconv.hip (``mg_modconv3x3_c64``: v_mfma_f32_32x32x16_bf16, weights resident in LDS,
-modulation applied while staging the halo tile, epilogue on the accumulators).  With ``styles = dcoefs = noise = None`` it is
-the discriminator's ``conv0`` + ``bias_act`` (reference :600-603).  Same roundings as the three-launch path (x*s to bf16, the
-convolution result to bf16, the fma sum to bf16), so the two agree to the order of the float32 accumulation.
+-- as separate launches three of them and six trips of the activation through HBM (modulation pass, library convolution,
+fused epilogue pass) -- in ONE launch of csrc/modconv.hip (``mg_modconv3x3_c64``: v_mfma_f32_32x32x16_bf16, the weights of a
+wave's output-channel half resident in its registers with the modulation folded into them, the input halo double-buffered in
+LDS by LDS-DMA, epilogue on the accumulators, two workgroups per CU).  With ``styles = dcoefs = noise = None`` it is the
+discriminator's ``conv0`` + ``bias_act`` (reference :600-603); with everything ``None`` and a linear activation a plain
+convolution, which is what the data gradient of these layers is (``conv3x3_c64(dy, flipped_transposed(w))``).
+Rounding points: the convolution result to bf16, dcoefs to bf16, the fma sum to bf16 -- as the three-launch path; the
+modulation is rounded on the WEIGHT (bf16(w * bf16(s)), the reference's own ``fused_modconv=True`` formulation, :91-93) where
+the three launches round x * s: equal on integer data bit for bit, within bf16 rounding otherwise.
 
-Scope: bf16, channels-last, 64 -> 64 channels, stride 1, padding 1, H % 8 == 0, W % 32 == 0 -- the 256x256 layers of the
+Scope: bf16, channels-last, 64 -> 64 channels, stride 1, padding 1, H % 4 == 0, W % 32 == 0 -- the 256x256 layers of the
 benchmark configuration, the largest activations of both networks.  Anything else keeps the three-launch path
 (``applicable()`` says which).
 
-Gradients.  A plain ``backward()`` is assembled from the kernels the three-launch path already uses, on the tensors the
-forward saved: the fused epilogue gradient (``mg_bwd_fused_nhwc``: d(conv out), d(dcoefs), d(bias), d(noise_strength) in one
-pass), the library's ``convolution_backward`` on the re-modulated input (one extra modulation pass instead of keeping x*s
-alive), and the fused modulation gradient.  Under ``create_graph=True`` (path-length regularisation) the backward re-runs the
-differentiable three-launch composition on the saved inputs, so gradients of any order exist.
+Gradients.  A plain ``backward()``: the fused epilogue gradient (``mg_bwd_fused_nhwc``: d(conv out), d(dcoefs), d(bias),
+d(noise_strength) in one pass), the data gradient through THIS kernel on the flipped, transposed weights, the library's
+weight gradient on the re-modulated input, and the fused modulation gradient.  Under ``create_graph=True`` (path-length
+regularisation) the backward re-runs the differentiable three-launch composition on the saved inputs, so gradients of any order
+exist.
+
+Measured at [32,64,256,256] (profiles/r03_modconv_microbench.log): forward 260 us against 635 us for the three launches
+(595 TFLOP/s), forward + backward 1411 against 1784 us; over the training step at batch 32: 616 against 633 ms
+(profiles/r03_bench_b32_modconv_{on,off}.json).  On by default; ``MG_MODCONV=0`` switches it off.
 """
 import os
 
@@ -30,11 +38,8 @@ from . import bias_act as _ba
 from . import conv2d_gradfix
 from . import modconv_epilogue as _me
 
-# Module switch.  OFF by default: in isolation the kernel beats the three launches it replaces (forward 380 vs 624 us at
-# [32,64,256,256], profiles/r02_modconv_microbench.log) but over the whole training step the gain is inside the run-to-run noise
-# (690 vs 684 ms, profiles/r02_bench_b32_modconv_{on,off}.json): its phases -- stage, MFMA, epilogue -- run one after the other at
-# one workgroup per CU.  MG_MODCONV=1 turns it on; the parity tests exercise it either way.
-enabled = os.environ.get('MG_MODCONV', '0') == '1'
+enabled = os.environ.get('MG_MODCONV', '1') != '0'
+reconstruct = os.environ.get('MG_MODCONV_RECON', '1') != '0'     # rebuild the raw convolution output from y in the backward pass
 
 
 def applicable(x, weight, up=1, down=1):
@@ -118,7 +123,9 @@ def _fused(act, alpha, gain, clamp):
             # the weight gradient of the convolution reads x * s: written by the same launch (one more store of the tile
             # while it is in registers) rather than recomputed in the backward pass (a read and a write)
             want_xs = False     # (round 3: the kernel folds the modulation into its weights; x * s is recomputed where the library's weight gradient needs it)
-            want_conv = need_bwd and dcoefs is not None      # only the demodulation gradient reads the raw convolution output
+            # the demodulation gradient sums dpre * (raw convolution output): rebuilt from y inside the backward kernel
+            # (mg_bwd_fused_nhwc_y, recon) instead of written here and read there -- two passes over the activation less
+            want_conv = need_bwd and dcoefs is not None and not reconstruct
             with conv2d_gradfix._timed_call(x, (64, 64, 3, 3), 1, 'fwd [mg_modconv3x3_c64]'):
                 y, yconv, xs = _launch(x, wc, s32, d32, nz32, nz_stride, st32, b16, want_conv, want_xs, idx, alpha, gain, clamp)
             if need_bwd:
@@ -139,16 +146,18 @@ def _fused(act, alpha, gain, clamp):
             has_s, has_d, has_nz, has_st, has_b = ctx.has
             need = ctx.needs_input_grad          # x, w, styles, dcoefs, noise, strength, b
             if torch.is_grad_enabled():
-                # create_graph=True: differentiate the three-launch composition of the saved inputs
-                ins = [x, w] + [t for t, h_ in ((styles, has_s), (dcoefs, has_d), (noise, has_nz), (strength, has_st), (b, has_b)) if h_]
-                live = [t for t in ins if t.requires_grad]
+                # create_graph=True: differentiate the three-launch composition of the saved inputs -- towards the inputs THIS pass
+                # needs only (the regularisers ask for ws / the image: no weight, no bias).  Asking for more is not just wasted work:
+                # the prepared weight is one output of the network's weight-preparation node, and a request for its gradient makes
+                # the engine run every backward node between x and that node, i.e. the whole generator below this layer.
+                full = [x, w, styles if has_s else None, dcoefs if has_d else None, noise if has_nz else None,
+                        strength if has_st else None, b if has_b else None]
+                live = [t for t, nd in zip(full, need) if t is not None and nd and t.requires_grad]
                 with torch.enable_grad():
                     out = _composition(x, w, styles if has_s else None, dcoefs if has_d else None, noise if has_nz else None,
                                        strength if has_st else None, b if has_b else None, act, alpha, gain, clamp)
-                    grads = torch.autograd.grad([out], live, [dy], create_graph=True, allow_unused=True)
+                    grads = torch.autograd.grad([out], live, [dy], create_graph=True, allow_unused=True) if live else ()
                 table = {id(t): g for t, g in zip(live, grads)}
-                full = [x, w, styles if has_s else None, dcoefs if has_d else None, noise if has_nz else None,
-                        strength if has_st else None, b if has_b else None]
                 return tuple(table.get(id(t)) if (t is not None and nd) else None for t, nd in zip(full, need))
             n, c, h, wd = x.shape
             assert not (has_nz and need[4]), 'a noise tensor that wants its own gradient takes the three-launch path'
@@ -160,10 +169,13 @@ def _fused(act, alpha, gain, clamp):
             acc = torch.zeros([2 * n * c + native.GS_SLOTS], dtype=torch.float32, device=x.device)
             gd_a, gb_a, gs_a = acc[:n * c], acc[n * c:2 * n * c], acc[2 * n * c:]
             d32 = dcoefs.to(torch.float32).contiguous() if has_d else None
+            recon = bool(want_gd and not yconv.numel())
+            b16 = b.detach().to(x.dtype).contiguous() if (recon and has_b) else None
             with native.guard(x.device):
-                native.check(native.lib().mg_bwd_fused_nhwc(
-                    native.ptr(dy), native.ptr(None if ident else y), native.ptr(yconv if want_gd else None), native.ptr(d32),
-                    native.ptr(nz32 if want_gs else None), native.ptr(dyc), native.ptr(gd_a if want_gd else None),
+                native.check(native.lib().mg_bwd_fused_nhwc_y(
+                    native.ptr(dy), native.ptr(y if (recon or not ident) else None), native.ptr(yconv if (want_gd and not recon) else None), native.ptr(d32),
+                    native.ptr(nz32 if (want_gs or (recon and has_nz)) else None), native.ptr(st32 if (recon and has_nz and has_st) else None),
+                    native.ptr(b16), int(recon), native.ptr(dyc), native.ptr(gd_a if want_gd else None),
                     native.ptr(gb_a if want_gb else None), native.ptr(gs_a if want_gs else None), native.dtype_code(x.dtype), idx, alpha, gain,
                     clamp, ctx.nz_stride, n, c, h * wd, native.stream_ptr(x.device)))
             gd = gd_a.reshape(n, c).to(dcoefs.dtype) if want_gd else None

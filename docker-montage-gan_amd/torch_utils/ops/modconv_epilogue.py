@@ -178,6 +178,134 @@ def modconv_epilogue(x, dcoefs=None, noise=None, b=None, act='lrelu', alpha=None
     return _epilogue_ref(x, dcoefs, noise, b, act, alpha, gain, None if clamp < 0 else clamp)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The up-sampling layers (SynthesisLayer with up=2, reference training/networks.py:299-313 -> conv2d_resample.py:123-144) end in
+#     x = upfirdn2d(conv_transpose2d(x, w, stride 2), f, padding, gain = 4)      # the 4x4 blur: read [r+1]^2, write r^2
+#     x = fma(x, dcoefs, noise) ; x = bias_act(x, b, lrelu, gain, clamp)         # read r^2, write r^2
+# ``blur_epilogue`` is both in ONE pass over the transposed convolution's output (mg_upfirdn2d_epilogue: the channels-last 1:1 FIR
+# kernels of csrc/upfirdn2d.hip with the epilogue applied to each output vector on its way out -- same rounding points: the
+# filter's result to x.dtype, dcoefs to x.dtype, the fma sum to x.dtype).  Backward (plain): the fused epilogue gradient with the
+# filter's output REBUILT from the saved y (mg_bwd_fused_nhwc_y, recon: the filtered tensor is never written), then the filter's
+# own gradient (upfirdn2d with the mirrored filter).  Under create_graph=True: the composition of the two differentiable ops.
+blur_fusion = __import__('os').environ.get('MG_BLUR_EPILOGUE', '1') != '0'
+
+
+def _blur_sizes(x, f, padding):
+    px0, px1, py0, py1 = padding
+    fh, fw = (int(f.shape[0]), int(f.shape[1])) if f.ndim == 2 else (int(f.shape[0]), int(f.shape[0]))
+    return fh, fw, int(x.shape[2]) + py0 + py1 - fh + 1, int(x.shape[3]) + px0 + px1 - fw + 1
+
+
+def blur_epilogue_applicable(x, f, padding, act):
+    if not (blur_fusion and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and _is_nhwc(x) and f is not None and f.ndim == 2
+            and f.shape[0] <= 4 and f.shape[1] <= 4 and act in ('linear', 'lrelu')):
+        return False
+    fh, fw, oh, ow = _blur_sizes(x, f, padding)
+    return oh >= 1 and ow >= 1 and x.numel() > 0
+
+
+_blur_cache = dict()
+
+
+def _blur_epilogue_hip(act, alpha, gain, clamp, padding, flip_filter, fgain):
+    key = (act, alpha, gain, clamp, tuple(padding), flip_filter, fgain)
+    if key in _blur_cache:
+        return _blur_cache[key]
+    idx = _ba.activation_funcs[act].cuda_idx
+    from . import upfirdn2d as _up
+    px0, px1, py0, py1 = padding
+
+    class BlurEpilogue(torch.autograd.Function):
+        """inputs: x (transposed-convolution output), f, dcoefs, noise (raw), strength (0-dim), b"""
+
+        @staticmethod
+        def forward(ctx, x, f, dcoefs, noise, strength, b):
+            n, c, ih, iw = x.shape
+            fh, fw, oh, ow = _blur_sizes(x, f, padding)
+            d32 = dcoefs.detach().to(torch.float32).contiguous() if dcoefs is not None else None
+            nz32, nz_stride, s32 = None, 0, None
+            if noise is not None:
+                assert noise.numel() in (oh * ow, n * oh * ow), 'noise must be [H,W] or [N,1,H,W]'
+                nz32 = noise.detach().to(torch.float32).contiguous()
+                nz_stride = oh * ow if noise.numel() == n * oh * ow and n > 1 else 0
+                if strength is not None:
+                    s32 = strength.detach().to(torch.float32).reshape(1).contiguous()
+            bb = b.detach().to(x.dtype).contiguous() if b is not None else None
+            f32 = f.detach().to(torch.float32)
+            y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            with native.guard(x.device):
+                native.check(native.lib().mg_upfirdn2d_epilogue(
+                    native.ptr(x), native.ptr(f32), native.ptr(y), native.dtype_code(x.dtype), native.I32x4(n, c, ih, iw), native.I32x2(fh, fw),
+                    native.I64x2(f32.stride(0), f32.stride(1)), native.I32x4(n, c, oh, ow), px0, py0, int(flip_filter), fgain,
+                    native.ptr(d32), native.ptr(nz32), native.ptr(s32), native.ptr(bb), nz_stride, idx, alpha, gain, clamp,
+                    native.stream_ptr(x.device)))
+            ctx.save_for_backward(x, f, dcoefs if dcoefs is not None else _ba._null_tensor, y, nz32 if nz32 is not None else _ba._null_tensor,
+                                  s32 if s32 is not None else _ba._null_tensor, noise if noise is not None else _ba._null_tensor,
+                                  strength if strength is not None else _ba._null_tensor, b if b is not None else _ba._null_tensor)
+            ctx.has = (dcoefs is not None, noise is not None, strength is not None, b is not None)
+            ctx.nz_stride = nz_stride
+            return y
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, f, dcoefs, y, nz32, s32, noise, strength, b = ctx.saved_tensors
+            has_d, has_nz, has_s, has_b = ctx.has
+            need = ctx.needs_input_grad          # x, f, dcoefs, noise, strength, b
+            if torch.is_grad_enabled():
+                full = [x, None, dcoefs if has_d else None, noise if has_nz else None, strength if has_s else None, b if has_b else None]
+                live = [t for t, nd in zip(full, need) if t is not None and nd and t.requires_grad]
+                with torch.enable_grad():
+                    yb = _up.upfirdn2d(x, f, padding=list(padding), flip_filter=flip_filter, gain=fgain)
+                    out = modconv_epilogue(yb, dcoefs if has_d else None, noise if has_nz else None, b if has_b else None, act=act, alpha=alpha,
+                                           gain=gain, clamp=None if clamp < 0 else clamp, noise_strength=strength if has_s else None)
+                    grads = torch.autograd.grad([out], live, [dy], create_graph=True, allow_unused=True) if live else ()
+                table = {id(t): g for t, g in zip(live, grads)}
+                return tuple(table.get(id(t)) if (t is not None and nd) else None for t, nd in zip(full, need))
+            assert not (has_nz and need[3]), 'a noise tensor that wants its own gradient takes the unfused path'
+            n, c, oh, ow = y.shape
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            want_gd, want_gb, want_gs = has_d and need[2], has_b and need[5], has_nz and has_s and need[4]
+            dxb = torch.empty_like(y)
+            acc = torch.zeros([2 * n * c + native.GS_SLOTS], dtype=torch.float32, device=y.device)
+            gd_a, gb_a, gs_a = acc[:n * c], acc[n * c:2 * n * c], acc[2 * n * c:]
+            d32 = dcoefs.to(torch.float32).contiguous() if has_d else None
+            b16 = b.detach().to(y.dtype).contiguous() if (want_gd and has_b) else None
+            with native.guard(y.device):
+                native.check(native.lib().mg_bwd_fused_nhwc_y(
+                    native.ptr(dy), native.ptr(y), None, native.ptr(d32), native.ptr(nz32 if (want_gs or (want_gd and has_nz)) else None),
+                    native.ptr(s32 if (want_gd and has_nz and has_s) else None), native.ptr(b16), int(want_gd), native.ptr(dxb),
+                    native.ptr(gd_a if want_gd else None), native.ptr(gb_a if want_gb else None), native.ptr(gs_a if want_gs else None),
+                    native.dtype_code(y.dtype), idx, alpha, gain, clamp, ctx.nz_stride, n, c, oh * ow, native.stream_ptr(y.device)))
+            gd = gd_a.reshape(n, c).to(dcoefs.dtype) if want_gd else None
+            gb = gb_a.reshape(n, c).sum(0).to(b.dtype) if want_gb else None
+            gs = gs_a.sum().to(strength.dtype) if want_gs else None
+            gx = None
+            if need[0]:     # the filter's own gradient (reference upfirdn2d.py:263-278): the same op, filter mirrored, padding recomputed
+                fh, fw = int(f.shape[0]), int(f.shape[1])
+                pb = [fw - px0 - 1, int(x.shape[3]) - ow + px0, fh - py0 - 1, int(x.shape[2]) - oh + py0]
+                gx = _up.upfirdn2d(dxb, f, padding=pb, flip_filter=(not flip_filter), gain=fgain)
+            return gx, None, gd, None, gs, gb
+
+    _blur_cache[key] = BlurEpilogue
+    return BlurEpilogue
+
+
+def blur_epilogue(x, f, padding, flip_filter=False, fgain=1.0, dcoefs=None, noise=None, b=None, act='lrelu', alpha=None, gain=None,
+                  clamp=None, noise_strength=None):
+    """modconv_epilogue(upfirdn2d(x, f, padding=padding, flip_filter=flip_filter, gain=fgain), dcoefs, noise, b, ...) -- one native
+    pass where ``blur_epilogue_applicable``, the two ops otherwise.  padding = [px0, px1, py0, py1]."""
+    spec = _ba.activation_funcs[act]
+    alpha = float(spec.def_alpha if alpha is None else alpha)
+    gain = float(spec.def_gain if gain is None else gain)
+    if blur_epilogue_applicable(x, f, padding, act):
+        _ba._init()
+        return _blur_epilogue_hip(act, alpha, gain, float(-1 if clamp is None else clamp), tuple(int(v) for v in padding), bool(flip_filter),
+                                  float(fgain)).apply(x, f, dcoefs, noise, noise_strength, b)
+    from . import upfirdn2d as _up
+    yb = _up.upfirdn2d(x, f, padding=list(padding), flip_filter=flip_filter, gain=fgain)
+    return modconv_epilogue(yb, dcoefs, noise, b, act=act, alpha=alpha, gain=gain, clamp=clamp, noise_strength=noise_strength)
+
+
 class _ChannelScale(torch.autograd.Function):
     """y = x * s[N,C,1,1] on the native path; backward = one fused kernel (dx = dy*s, ds = sum_hw dy*x)."""
 

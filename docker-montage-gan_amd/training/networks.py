@@ -336,6 +336,14 @@ class SynthesisLayer(torch.nn.Module):
                 return modconv3x3.fused_modconv3x3(x, wc, st, dcoefs, noise_raw, self.noise_strength if noise_raw is not None else None,
                                                    self.bias, act=self.activation, gain=act_gain, clamp=act_clamp)
             y = modconv_epilogue.channel_scale(x, st)
+            if self.up > 1 and self.activation in ('linear', 'lrelu') and modconv_epilogue.blur_fusion and modconv_epilogue._is_nhwc(y):
+                # up-sampling layer on channels-last 16-bit tensors: the blur that ends conv2d_resample and the epilogue in ONE pass
+                strength = self.noise_strength if noise_raw is not None else None
+                return conv2d_resample.conv2d_resample(
+                    x=y, w=wc, f=self.resample_filter, up=self.up, padding=self.padding, flip_weight=flip_weight,
+                    tail=lambda t, f, pad, fgain, flip: modconv_epilogue.blur_epilogue(
+                        t, f, pad, flip_filter=flip, fgain=fgain, dcoefs=dcoefs, noise=noise_raw, b=self.bias, act=self.activation,
+                        gain=act_gain, clamp=act_clamp, noise_strength=strength))
             y = conv2d_resample.conv2d_resample(x=y, w=wc, f=self.resample_filter, up=self.up,
                                                 padding=self.padding, flip_weight=flip_weight)
             if y.is_contiguous() or modconv_epilogue._is_nhwc(y):

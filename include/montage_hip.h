@@ -186,6 +186,15 @@ int mg_fma_bias_act_nhwc(const void* x, const float* d, const float* noise, cons
 int mg_bwd_fused_nhwc(const void* dy, const void* yref, const void* x, const float* d, const float* noise,
                       void* dx, float* gd, float* gb_partial, float* gs, int dtype, int act, float alpha, float gain,
                       float clamp, int64_t noise_stride_n, int32_t n, int32_t c, int32_t hw, void* stream);
+/* The same with the epilogue's input x REBUILT from its saved output (recon != 0, x = NULL, act linear or lrelu, gain != 0):
+ *     pre = yref / gain  (/ alpha where negative),   x = (pre - noise * *strength - bias[c]) / T(d[n,c])
+ * -- what gd sums over -- so that a producer that fuses the epilogue into its own store (the matrix-core convolution, the
+ * blur of the up-sampling layers) need not write its pre-epilogue result at all.  bias [C] in the activation dtype or NULL,
+ * strength a device scalar or NULL (1).  recon = 0 is mg_bwd_fused_nhwc. */
+int mg_bwd_fused_nhwc_y(const void* dy, const void* yref, const void* x, const float* d, const float* noise,
+                        const float* strength, const void* bias, int recon, void* dx, float* gd, float* gb_partial, float* gs,
+                        int dtype, int act, float alpha, float gain, float clamp, int64_t noise_stride_n, int32_t n, int32_t c,
+                        int32_t hw, void* stream);
 
 /* ---- demodulation coefficients ---------------------------------------------------
  * d[n,o] = rsqrt(sum_i s[n,i]^2 * wsq[o,i] + 1e-8), wsq[o,i] = sum_k w[o,i,k]^2 -- the demodulation of
@@ -249,6 +258,19 @@ int mg_modconv3x3_c64(const void* x, const void* w, const float* s, const float*
 /* diagnostics: while `buf` (device memory, uint64[8]) is set, workgroup 0 of mg_modconv3x3_c64 leaves its cycle counts per phase
  * (stage, prefetch issue, MFMA loop, epilogue, store) there; NULL switches it off (tools/bench_modconv.py). */
 void mg_modconv_debug_timing(void* buf);
+
+/*
+ * mg_upfirdn2d_epilogue: the 4x4 blur that ends an up-sampling SynthesisLayer (reference training/networks.py:299-313 through
+ * torch_utils/ops/conv2d_resample.py:123-144: upfirdn2d(x, f, padding, gain) on the transposed convolution's output) and the layer's
+ * epilogue -- fma(x, dcoefs, noise * strength), bias_act(b, act, alpha, act_gain, clamp) -- in one pass: up = down = 1, filter <= 4x4,
+ * float16 / bfloat16 dense channels-last x [N,C,inH,inW] -> y [N,C,outH,outW] (out = in + pad0 + pad1 - f + 1; the caller sizes y),
+ * d [N,C] float32 or NULL, noise [N,outH,outW] / [outH,outW] float32 (noise_stride_n = outH*outW / 0) or NULL, strength device scalar
+ * or NULL (1), b [C] in the activation dtype or NULL.  Every intermediate is rounded where the separate launches round it.
+ */
+int mg_upfirdn2d_epilogue(const void* x, const float* f, void* y, int dtype, const int32_t x_size[4], const int32_t f_size[2],
+                          const int64_t f_stride[2], const int32_t y_size[4], int padx0, int pady0, int flip, float gain,
+                          const float* d, const float* noise, const float* strength, const void* b, int64_t noise_stride_n,
+                          int act, float alpha, float act_gain, float clamp, void* stream);
 
 /*
  * mg_torgb_nhwc_{fwd,bwd}: the generator's ToRGB layer on channels-last float16 / bfloat16 activations, one pass each way

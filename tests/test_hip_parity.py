@@ -613,6 +613,73 @@ def test_modconv_epilogue_matches_fma_then_bias_act(native, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_blur_epilogue_one_pass_matches_blur_then_epilogue(native, dtype):
+    """modconv_epilogue.blur_epilogue (mg_upfirdn2d_epilogue: the 4x4 blur that ends an up-sampling layer + the layer's epilogue in
+    one pass; backward through mg_bwd_fused_nhwc_y with the blurred tensor rebuilt from the saved output) against upfirdn2d followed
+    by modconv_epilogue.  Integer data: bit for bit forward (both FIR kernels: the block form and, from 192 output rows on, the
+    row-streaming form); random data: forward within two ulps, gradients within the bounds of the epilogue test -- the demodulation
+    gradient additionally carries the rounding of y (it is summed over the REBUILT filter output)."""
+    E, U = op('modconv_epilogue'), op('upfirdn2d')
+    g = torch.Generator(device=DEV).manual_seed(9)
+    f = U.setup_filter([1, 3, 3, 1]).to(DEV)
+    for (n, c, h, w, full) in [(2, 64, 33, 33, True), (3, 16, 17, 41, True), (1, 64, 257, 129, True), (2, 128, 65, 65, False), (1, 32, 200, 24, False)]:
+        for exact in (True, False):
+            oh, ow = h - 1, w - 1
+            if exact:       # the filter [1,3,3,1]^2 / 64 * gain 4 = integers / 16: products and sums stay exact in both 16-bit types
+                x = (torch.randint(-2, 3, [n, c, h, w], device=DEV, generator=g) * 16).to(dtype)
+                d = torch.randint(1, 3, [n, c], device=DEV, generator=g).float()
+                nz = torch.randint(-2, 3, [n, 1, oh, ow], device=DEV, generator=g).float()
+                st = torch.tensor(2.0, device=DEV)
+                b = torch.randint(-3, 4, [c], device=DEV, generator=g).float()
+            else:
+                x = torch.randn([n, c, h, w], device=DEV, generator=g).to(dtype)
+                d = torch.rand([n, c], device=DEV, generator=g) + 0.5
+                nz = torch.randn([n, 1, oh, ow], device=DEV, generator=g)
+                st = torch.tensor(0.3, device=DEV)
+                b = torch.randn([c], device=DEV, generator=g) * 0.3
+            x = x.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            args = dict(dcoefs=d.requires_grad_(True), noise=nz, b=b.requires_grad_(True), noise_strength=st.requires_grad_(True)) if full else dict(b=b.requires_grad_(True))
+            leaves = [x] + [v for v in args.values() if v.requires_grad]
+            kw = dict(act='lrelu', gain=float(np.sqrt(2)) if not exact else 2.0, clamp=None if not exact else 40.0)
+            before = native.launch_count(native.K_UPFIRDN2D_NHWC)
+            assert E.blur_epilogue_applicable(x, f, [1, 1, 1, 1], 'lrelu')
+            y = E.blur_epilogue(x, f, [1, 1, 1, 1], fgain=4.0, **args, **kw)
+            assert native.launch_count(native.K_UPFIRDN2D_NHWC) == before + 1 and tuple(y.shape) == (n, c, oh, ow)
+            ref = E.modconv_epilogue(U.upfirdn2d(x, f, padding=[1, 1, 1, 1], gain=4.0), args.get('dcoefs'), args.get('noise'), args['b'],
+                                     noise_strength=args.get('noise_strength'), **kw)
+            what = f'{(n, c, h, w, full)} exact={exact}'
+            if exact:
+                assert torch.equal(y, ref), (what, float((y.float() - ref.float()).abs().max()))
+            else:
+                close_lowp(y.float().detach().cpu().numpy(), ref.float().detach().cpu().numpy(), dtype, what)
+            dy = (torch.randint(-2, 3, y.shape, device=DEV, generator=g) if exact else torch.randn(y.shape, device=DEV, generator=g)).to(dtype)
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            g1, g2 = torch.autograd.grad([y], leaves, [dy]), torch.autograd.grad([ref], leaves, [dy])
+            for u, v, leaf in zip(g1, g2, leaves):
+                nm = 'x' if leaf is x else 'd' if (full and leaf is args['dcoefs']) else 'st' if (full and leaf is args.get('noise_strength')) else 'b'
+                if exact and nm != 'd':
+                    assert torch.equal(u.float(), v.float()), f'{what}: grad {nm}'
+                else:
+                    # d: summed over the filter output rebuilt from y -- exact only where y was not rounded
+                    close_lowp(u.float().cpu().numpy(), v.float().cpu().numpy(), dtype, f'{what}: grad {nm}', tol=(8 if nm == 'd' else 4) * LOWP_TOL[dtype])
+    # second order (create_graph): the differentiable composition inside the same Function
+    x = torch.randn([2, 16, 17, 17], device=DEV, generator=g).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    d = (torch.rand([2, 16], device=DEV, generator=g) + 0.5).requires_grad_(True)
+    b = torch.zeros([16], device=DEV, requires_grad=True)
+    outs = []
+    for fused in (True, False):
+        E.blur_fusion = fused
+        try:
+            y = E.blur_epilogue(x, f, [1, 1, 1, 1], fgain=4.0, dcoefs=d, b=b, act='lrelu', clamp=256)
+            gx, = torch.autograd.grad([y.float().square().sum()], [x], create_graph=True)
+            outs.append(torch.autograd.grad([gx.float().square().sum()], [x, d]))
+        finally:
+            E.blur_fusion = True
+    for u, v in zip(*outs):
+        close_lowp(u.float().cpu().numpy(), v.float().cpu().numpy(), dtype, 'second order', tol=8 * LOWP_TOL[dtype])
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 def test_torgb_one_pass_matches_the_four_launches(native, dtype):
     """ops/torgb.py: ToRGB + the cast to the float32 image path as one native pass against the composition it replaces
     (channel_scale -> 1x1 convolution -> bias_act(clamp) -> .to(float32)): values, all four first-order gradients, and the
@@ -1280,10 +1347,12 @@ def test_fused_modconv3x3_values_and_gradients(native, modconv_on, with_mod):
         for i, (a, r) in enumerate(zip(got, want)):
             scale = float(r.float().abs().max()) + 1e-6
             err = float((a.float() - r.float()).abs().max())
+            name = names[i - 1] if (not second and i) else ''
+            # the noise-strength gradient is ONE number, sum_px dpre * noise: ~N^0.5 large with ~0.5 % of its N terms flipped
             bound = 3e-2 if (i == 0 and not second) else 0.2
             assert err <= bound * scale, (second, i, names[i - 1] if (not second and i) else i, err, scale)
             mean = float((a.float() - r.float()).abs().mean())
-            assert mean <= (4e-3 if (i == 0 and not second) else 1.5e-2) * scale, (second, i, names[i - 1] if (not second and i) else i, mean, scale)
+            assert mean <= (4e-3 if (i == 0 and not second) else 0.2 if name == 'st' else 1.5e-2) * scale, (second, i, name, mean, scale)
 
 
 def test_synthesis_and_discriminator_take_the_fused_kernel(native, modconv_on):
