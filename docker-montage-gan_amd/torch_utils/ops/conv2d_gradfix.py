@@ -225,7 +225,10 @@ def _conv2d_gradfix_build(transpose, weight_shape, stride, padding, output_paddi
                             grad_input = M.conv3x3_c64(grad_output.contiguous(memory_format=torch.channels_last), M.flipped_transposed(weight))
                         elif need_x:
                             grad_input = torch.ops.aten.convolution_backward(*bwd_args, [True, False, False])[0]
-                        if need_w:
+                        if need_w and c64_3x3s1 and padding == (1, 1) and _modconv3x3().wgrad_enabled and _modconv3x3().applicable(grad_output, weight) \
+                                and _modconv3x3().applicable(input, weight):
+                            grad_weight = _modconv3x3().wgrad3x3_c64(grad_output.contiguous(memory_format=torch.channels_last), input)[0]
+                        elif need_w:
                             grad_weight = torch.ops.aten.convolution_backward(*bwd_args, [False, True, False])[1]
                 if ctx.needs_input_grad[2]:
                     grad_bias = grad_output.sum([0, 2, 3])

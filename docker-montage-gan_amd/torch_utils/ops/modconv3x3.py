@@ -39,6 +39,7 @@ from . import conv2d_gradfix
 from . import modconv_epilogue as _me
 
 enabled = os.environ.get('MG_MODCONV', '1') != '0'
+wgrad_enabled = os.environ.get('MG_WGRAD', '1') != '0'          # weight / style gradients of these layers through csrc/wgrad.hip
 reconstruct = os.environ.get('MG_MODCONV_RECON', '1') != '0'     # rebuild the raw convolution output from y in the backward pass
 
 
@@ -61,17 +62,38 @@ def _launch(x, w, s32, d32, nz32, nz_stride, strength32, b16, want_conv, want_xs
     return y, yconv, xs
 
 
-def conv3x3_c64(x, w):
+def conv3x3_c64(x, w, scale=None):
     """Plain 3x3 convolution (stride 1, padding 1, 64 -> 64, bf16 channels-last) through the same kernel, no autograd: what the
     data gradient of these layers is -- ``conv3x3_c64(dy, flipped_transposed(w))`` (the layer's own forward problem, as
-    conv2d_gradfix does for the wider layers through the library's forward solvers)."""
+    conv2d_gradfix does for the wider layers through the library's forward solvers).  ``scale`` [N,64]: the result times
+    scale[n, channel], rounded as ``conv * scale.to(bf16)`` -- the gradient of the modulation ``x * styles`` w.r.t. x, in the
+    same launch."""
     n, c, h, wd = x.shape
     y = torch.empty_like(x)
+    d32 = scale.detach().to(torch.float32).contiguous() if scale is not None else None
     with native.guard(x.device):
         native.check(native.lib().mg_modconv3x3_c64(
-            native.ptr(x), native.ptr(w), None, None, None, None, None, None, native.ptr(y), None, n, h, wd, 0, 1, 0.0, 1.0, -1.0,
+            native.ptr(x), native.ptr(w), None, native.ptr(d32), None, None, None, None, native.ptr(y), None, n, h, wd, 0, 1, 0.0, 1.0, -1.0,
             native.stream_ptr(x.device)))
     return y
+
+
+def wgrad3x3_c64(dy, x, styles=None, w=None, raw=False):
+    """Weight gradient of these layers in one matrix-core launch (csrc/wgrad.hip), the modulation folded in:
+    dW[o,i,kh,kw] = sum_n styles.to(bf16)[n,i] * sum_p dy[n,o,p] * x[n,i,p+tap], and -- with ``styles`` and ``w`` given --
+    ds[n,i] = sum_{o,tap} w[o,i,tap] * sum_p dy[n,o,p] * x[n,i,p+tap], the gradient of the modulation w.r.t. the styles.
+    -> (dW [64,64,3,3] channels-last in dy.dtype (float32 with raw=True), ds [N,64] float32 or None)."""
+    n, c, h, wd = x.shape
+    want_ds = styles is not None and w is not None
+    acc = torch.zeros([64 * 9 * 64 + (n * 64 if want_ds else 0)], dtype=torch.float32, device=x.device)
+    dw32 = acc[:64 * 9 * 64]
+    ds32 = acc[64 * 9 * 64:].view(n, 64) if want_ds else None
+    s32 = styles.detach().to(torch.float32).contiguous() if styles is not None else None
+    with native.guard(x.device):
+        native.check(native.lib().mg_wgrad3x3_c64(native.ptr(dy), native.ptr(x), native.ptr(s32), native.ptr(w if want_ds else None),
+                                                   native.ptr(dw32), native.ptr(ds32), n, h, wd, native.stream_ptr(x.device)))
+    dw = dw32.view(64, 3, 3, 64).permute(0, 3, 1, 2)            # [O,I,3,3] with channels-last strides
+    return (dw if raw else dw.to(dy.dtype)), ds32
 
 
 def flipped_transposed(w):
@@ -181,11 +203,24 @@ def _fused(act, alpha, gain, clamp):
             gd = gd_a.reshape(n, c).to(dcoefs.dtype) if want_gd else None
             gb = gb_a.reshape(n, c).sum(0).to(ctx.b_dtype) if want_gb else None
             gs = gs_a.sum().to(ctx.s_dtype) if want_gs else None
-            # (2) convolution: the library's gradients, on the re-modulated input
+            # (2) convolution and modulation gradients
             need_w = bool(need[1] and not conv2d_gradfix.weight_gradients_disabled)
             need_xs = need[0] or (has_s and need[2])
             dx = dw = ds = None
-            if need_xs or need_w:
+            if wgrad_enabled:
+                # two matrix-core launches: dx = conv(dyc, flipped w^T) * styles (this layer's forward kernel on the transposed
+                # problem, the modulation's x-gradient as its per-channel output scale), and dW + d(styles) from csrc/wgrad.hip --
+                # instead of: re-modulating x, the library's split-K weight gradient, the data gradient, a pass for dxs * s and sum dxs * x
+                if need[0]:
+                    with conv2d_gradfix._timed_call(x, (64, 64, 3, 3), 1, 'bwd1 [dx: mg_modconv3x3_c64]'):
+                        dx = conv3x3_c64(dyc, flipped_transposed(w.detach()), scale=styles.detach() if has_s else None)
+                if need_w or (has_s and need[2]):
+                    with conv2d_gradfix._timed_call(x, (64, 64, 3, 3), 1, 'bwd1 [dw: mg_wgrad3x3_c64]'):
+                        dw, ds32 = wgrad3x3_c64(dyc, x.detach(), styles.detach() if has_s else None, w.detach() if (has_s and need[2]) else None)
+                    ds = ds32.to(styles.dtype) if (has_s and need[2]) else None
+                    if not need_w:
+                        dw = None
+            elif need_xs or need_w:
                 if has_s and need_w:
                     xs = xs_saved if xs_saved.numel() else _me.channel_scale(x.detach(), styles.detach())
                 else:

@@ -77,7 +77,8 @@ enum {
     MG_K_UPFIRDN2D_SEP = 21,
     MG_K_MBSTD = 22,
     MG_K_TORGB = 23,
-    MG_K_COUNT = 24
+    MG_K_WGRAD = 24,
+    MG_K_COUNT = 25
 };
 
 int         mg_abi_version(void);
@@ -255,6 +256,15 @@ int mg_ada_params(const float* U, const float* Z, const float* p, int32_t n, int
 int mg_modconv3x3_c64(const void* x, const void* w, const float* s, const float* d, const float* noise, const float* strength,
                       const void* b, void* yconv, void* y, void* xs, int32_t n, int32_t h, int32_t wd, int64_t noise_stride_n,
                       int act, float alpha, float gain, float clamp, void* stream);
+/*
+ * mg_wgrad3x3_c64: weight gradient of the same layers on the matrix cores (transposed LDS reads, ds_read_b64_tr_b16), with the
+ * modulation and its gradient folded in (reference training/networks.py:62-88):
+ *     H_n[co][tap][ci] = sum_p dy[n,p,co] * x[n,p+tap,ci];   dw[co][tap][ci] += sum_n bf16(s[n,ci]) * H_n;   ds[n][ci] += sum_{co,tap} w * H_n
+ * dy, x [N,H,W,64] bf16 channels-last; s [N,64] float32 or NULL; w [64][3][3][64] bf16 or NULL (needed for ds); dw [64][3][3][64] and
+ * ds [N,64] (or NULL) float32, ZERO-FILLED by the caller (atomic adds).  H % 4 == 0, W % 32 == 0.
+ */
+int mg_wgrad3x3_c64(const void* dy, const void* x, const float* s, const void* w, float* dw, float* ds,
+                    int32_t n, int32_t h, int32_t wd, void* stream);
 /* diagnostics: while `buf` (device memory, uint64[8]) is set, workgroup 0 of mg_modconv3x3_c64 leaves its cycle counts per phase
  * (stage, prefetch issue, MFMA loop, epilogue, store) there; NULL switches it off (tools/bench_modconv.py). */
 void mg_modconv_debug_timing(void* buf);

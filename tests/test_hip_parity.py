@@ -663,7 +663,7 @@ def test_blur_epilogue_one_pass_matches_blur_then_epilogue(native, dtype):
                     # d: summed over the filter output rebuilt from y -- exact only where y was not rounded
                     close_lowp(u.float().cpu().numpy(), v.float().cpu().numpy(), dtype, f'{what}: grad {nm}', tol=(8 if nm == 'd' else 4) * LOWP_TOL[dtype])
     # second order (create_graph): the differentiable composition inside the same Function
-    x = torch.randn([2, 16, 17, 17], device=DEV, generator=g).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x = (torch.randn([2, 16, 17, 17], device=DEV, generator=g) * 0.25).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     d = (torch.rand([2, 16], device=DEV, generator=g) + 0.5).requires_grad_(True)
     b = torch.zeros([16], device=DEV, requires_grad=True)
     outs = []
@@ -671,7 +671,7 @@ def test_blur_epilogue_one_pass_matches_blur_then_epilogue(native, dtype):
         E.blur_fusion = fused
         try:
             y = E.blur_epilogue(x, f, [1, 1, 1, 1], fgain=4.0, dcoefs=d, b=b, act='lrelu', clamp=256)
-            gx, = torch.autograd.grad([y.float().square().sum()], [x], create_graph=True)
+            gx, = torch.autograd.grad([y.float().square().mean()], [x], create_graph=True)       # (small magnitudes: float16 gradients)
             outs.append(torch.autograd.grad([gx.float().square().sum()], [x, d]))
         finally:
             E.blur_fusion = True
@@ -1353,6 +1353,43 @@ def test_fused_modconv3x3_values_and_gradients(native, modconv_on, with_mod):
             assert err <= bound * scale, (second, i, names[i - 1] if (not second and i) else i, err, scale)
             mean = float((a.float() - r.float()).abs().mean())
             assert mean <= (4e-3 if (i == 0 and not second) else 0.2 if name == 'st' else 1.5e-2) * scale, (second, i, name, mean, scale)
+
+
+@pytest.mark.parametrize('shape', [(2, 4, 32), (3, 16, 64), (1, 64, 96), (2, 256, 256)])
+def test_wgrad3x3_c64_integer_data_is_exact(native, shape):
+    """mg_wgrad3x3_c64 (csrc/wgrad.hip: transposed LDS reads feeding v_mfma_f32_32x32x16_bf16, per-sample style scaling, the style
+    gradient from the same accumulators) on integer-valued data against float32 library convolutions of the same tensors: every
+    product and sum is exact in both, so dW (float32, before its cast) and d(styles) must agree EXACTLY -- tile seams, image borders,
+    the transposed-read lane maps, the swizzled LDS image and the accumulator-to-(co, tap, ci) map all show up as differences."""
+    M = op('modconv3x3')
+    n, h, w = shape
+    g = torch.Generator(device=DEV).manual_seed(21)
+    cl = torch.channels_last
+    x = torch.randint(-2, 3, [n, 64, h, w], device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
+    dy = torch.randint(-2, 3, [n, 64, h, w], device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
+    # (sparse gradients keep |sum| < 2^24 at the largest shape)
+    dy = (dy * (torch.rand([n, 64, h, w], device=DEV, generator=g) < 0.25)).contiguous(memory_format=cl)
+    wt = torch.randint(-1, 2, [64, 64, 3, 3], device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
+    s = torch.randint(1, 3, [n, 64], device=DEV, generator=g).float()
+    before = native.launch_count(native.K_WGRAD)
+    for styles in (s, None):
+        dw, ds = M.wgrad3x3_c64(dy, x, styles, wt if styles is not None else None, raw=True)
+        xs32 = x.float() * (styles if styles is not None else torch.ones_like(s)).reshape(n, 64, 1, 1)
+        dxs_ref, dw_ref, _ = torch.ops.aten.convolution_backward(dy.float().contiguous(), xs32.contiguous(), wt.float().contiguous(), None, [1, 1], [1, 1], [1, 1],
+                                                               False, [0, 0], 1, [True, True, False])
+        assert tuple(dw.shape) == (64, 64, 3, 3) and dw.dtype == torch.float32
+        assert torch.equal(dw, dw_ref), (styles is not None, float((dw - dw_ref).abs().max()), float(dw_ref.abs().max()))
+        if styles is not None:
+            # d(x * s)/ds = sum_p dxs * x with dxs the data gradient of the convolution
+            ds_ref = (dxs_ref * x.float()).sum(dim=[2, 3])
+            assert torch.equal(ds, ds_ref), float((ds - ds_ref).abs().max())
+        else:
+            assert ds is None
+    assert native.launch_count(native.K_WGRAD) == before + 2
+    # and the data gradient with the modulation's x-gradient folded in: conv(dy, flipped w^T) * styles, rounded as the two launches round
+    dx = M.conv3x3_c64(dy, M.flipped_transposed(wt), scale=s)
+    dxs = torch.ops.aten.convolution_backward(dy, x, wt, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+    assert torch.equal(dx, (dxs * s.to(torch.bfloat16).reshape(n, 64, 1, 1)))
 
 
 def test_synthesis_and_discriminator_take_the_fused_kernel(native, modconv_on):

@@ -320,7 +320,16 @@ def test_recorded_phases_equal_the_eager_loop(ada):
     deviation never came from the recordings (each phase, replayed from saved state, reproduces its eager execution to 1e-7 on
     this configuration: profiles/r03_graph_probe_all_toy.log).  Here Adam runs with eps = 1e-3, which keeps the update a smooth
     function of the gradient: the arms must then agree tightly, and a wrong replay (stale inputs, other random draws, a skipped
-    step) still shows as an O(1) deviation.  No retry."""
+    step) still shows as an O(1) deviation.  No retry.
+
+    What is asserted, and what is only printed.  The proof that a recording equals the eager phase is PhaseGraphs' own: every
+    phase is executed eagerly twice and replayed three times FROM THE SAME SAVED STATE AND RANDOM DRAWS, and the deviations are
+    asserted below (< 1e-2 of the update; measured 1e-8 ... 2e-3).  Across whole arms -- which start from the same seed but
+    accumulate their own rounding history -- the weights, the EMA weights and the report counters are asserted against the
+    eager-vs-eager spread.  The gradients of the second iteration's global_Dmain are printed, not asserted: between two EAGER
+    arms they are bimodal on this toy (profiles/r03_graph_test_arms.log: 0.001-0.009 in five of ten pairs, 0.20-0.67 in the
+    other five, with and without ADA, with every native kernel switch on or off), so a bound derived from ONE eager pair says
+    nothing about the recorded arm -- the recorded arm lands in either cluster at the same rate."""
     AU = mod('training.augment')
     TS = mod('torch_utils.training_stats')
     smooth_adam = {k: dict(class_name='torch.optim.Adam', lr=0.0025, betas=[0, 0.99], eps=1e-3)
@@ -364,7 +373,9 @@ def test_recorded_phases_equal_the_eager_loop(ada):
         (w0, e0, s0, g0), (w1, e1, s1, g1) = arm(False), arm(False)
         w2, e2, s2, g2 = arm(True)
         assert len(w0) == len(w2) and len(g0) == len(g2)
-        for name, a, b, c, floor in (('first replayed gradients', g0, g1, g2, 2e-2), ('weights', w0, w1, w2, 1e-3), ('ema weights', e0, e1, e2, 1e-3)):
+        print(f'first replayed gradients (information): recorded-vs-eager {dist(g0, g2):.4g}, eager-vs-eager {dist(g0, g1):.4g}')
+        assert all(bool(torch.isfinite(g).all()) for g in g2)
+        for name, a, b, c, floor in (('weights', w0, w1, w2, 1e-3), ('ema weights', e0, e1, e2, 1e-3)):
             spread, got = dist(a, b), dist(a, c)
             print(f'{name}: recorded-vs-eager {got:.4g}, eager-vs-eager {spread:.4g}')
             assert got <= 4 * spread + floor, (name, got, spread)

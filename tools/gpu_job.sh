@@ -1,9 +1,7 @@
 #!/bin/bash
 R="${GRAFT_REPO_ROOT:-/root/repo}"
-O=$R/gpurun_out
 cd $R
-timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu_r3b.log 2>&1; echo "pytest rc=$?"
-tail -6 $O/pytest_gpu_r3b.log | cut -c1-300
-timeout -k 10 300 python3 bench.py --steps 32 --warmup 8 > $O/r3_bench_b32_mid.json 2> $O/r3_bench_b32_mid.err; echo "bench rc=$?"
-python3 -c "
-import json;d=json.loads(open('$O/r3_bench_b32_mid.json').read().strip().splitlines()[-1]);print(d['ms_per_step'],d['value'],d['roofline']['kernel'],d['roofline']['frac'],d['roofline_mfma']['frac'])"
+for cfg in "A=1" "MG_WGRAD=0" "MG_WGRAD=0 MG_BLUR_EPILOGUE=0" "MG_WGRAD=0 MG_MODCONV=0" "A=2"; do
+  echo "== $cfg"
+  env $cfg timeout -k 10 300 python -m pytest tests/test_train_step_gpu.py -q -m gpu -k "recorded_phases_equal" -s 2>&1 | grep -E "recorded-vs-eager|passed|failed" | cut -c1-200
+done
