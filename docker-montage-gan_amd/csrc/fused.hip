@@ -436,7 +436,59 @@ template <class T> struct BnArgs {
 
 // One workgroup = one slice of the pixels of one sample.  256 % cv == 0, so a lane keeps the same channel vector
 // for the whole slice and its VEC running sums per reduction stay in registers; they meet in LDS at the end.
-template <class T, int A>
+//
+// What is read is a compile-time property (YREF: the saved output; XM: 0 nothing / 1 the epilogue's input x / 2 x rebuilt from
+// the saved output; NZ: the noise plane), and a slice that lies inside the sample runs rounds of BU pixels per lane with no
+// bounds test: tested at run time (`if (p.yref) ... = load`), every load of the round sat in its own basic block behind a
+// `s_waitcnt vmcnt(0)` -- 180 branches and one load in flight per lane (round 3: 3.7 TB/s of algorithmic bytes; the loads of a
+// round now issue back to back).  FULL = false is the same body with the bounds tests, for the last slice of a ragged sample.
+template <class T, int A, int YREF, int XM, int NZ, bool FULL, int BU>
+__device__ __forceinline__ void bn_round(const BnArgs<T>& p, const BaConst<float>& k, size_t base, uint32_t pix0, uint32_t ppi, uint32_t hi,
+                                         const float* nzp, const float (&dv)[16 / sizeof(T)], const float (&bv)[16 / sizeof(T)],
+                                         const float (&rdv)[16 / sizeof(T)], float rstr, float rgain, float ralpha,
+                                         float (&s_gd)[16 / sizeof(T)], float (&s_gb)[16 / sizeof(T)], float& s_gs)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    struct alignas(16) V { T v[VEC]; };
+    V vdy[BU], vy[BU], vx[BU];
+    float nz[BU];
+    #pragma unroll
+    for (int u = 0; u < BU; u++) {
+        const uint32_t pix = pix0 + u * ppi;
+        if (!FULL && pix >= hi) continue;
+        const size_t off = base + (size_t)pix * p.c;
+        vdy[u] = *(const V*)(p.dy + off);
+        if (YREF) vy[u] = *(const V*)(p.yref + off);
+        if (XM == 1) vx[u] = *(const V*)(p.x + off);
+        nz[u] = NZ ? nzp[pix] : 0.f;
+    }
+    #pragma unroll
+    for (int u = 0; u < BU; u++) {
+        const uint32_t pix = pix0 + u * ppi;
+        if (!FULL && pix >= hi) continue;
+        V out;
+        float srow = 0.f;
+        #pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            float g = to_acc<T>(vdy[u].v[e]);
+            if (YREF) g = ba_eval<float, A>(1, g, 0.f, 0.f, to_acc<T>(vy[u].v[e]), 1.f, k);
+            const float gq = to_acc<T>(from_acc<T>(g));        // autograd materialises dpre in T
+            out.v[e] = from_acc<T>(gq * dv[e]);
+            s_gb[e] += gq;
+            if (XM == 1) s_gd[e] += gq * to_acc<T>(vx[u].v[e]);
+            else if (XM == 2) {
+                float pre = to_acc<T>(vy[u].v[e]) * rgain;
+                if (A == 3 && pre < 0.f) pre *= ralpha;
+                s_gd[e] += gq * ((pre - nz[u] * rstr - bv[e]) * rdv[e]);
+            }
+            srow += gq;
+        }
+        if (NZ) s_gs += srow * nz[u];
+        *(V*)(p.dx + base + (size_t)pix * p.c) = out;
+    }
+}
+
+template <class T, int A, int YREF, int XM, int NZ>
 __global__ void __launch_bounds__(256) bwd_fused_nhwc_kernel(BnArgs<T> p)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -447,7 +499,7 @@ __global__ void __launch_bounds__(256) bwd_fused_nhwc_kernel(BnArgs<T> p)
     const uint32_t pl = threadIdx.x / p.cv, cvi = threadIdx.x - pl * p.cv, ppi = 256u / p.cv;
     const uint32_t lo = slice * p.slice_pix, hi = min(p.hw, lo + p.slice_pix);
     const size_t base = (size_t)n * p.hw * p.c + cvi * VEC;
-    const float* nzp = p.noise ? p.noise + (int64_t)n * p.noise_stride_n : nullptr;
+    const float* nzp = NZ ? p.noise + (int64_t)n * p.noise_stride_n : nullptr;
     float dv[VEC];
     #pragma unroll
     for (int e = 0; e < VEC; e++) dv[e] = 1.f;
@@ -461,12 +513,12 @@ __global__ void __launch_bounds__(256) bwd_fused_nhwc_kernel(BnArgs<T> p)
     float s_gd[VEC], s_gb[VEC], s_gs = 0.f;
     #pragma unroll
     for (int e = 0; e < VEC; e++) { s_gd[e] = 0.f; s_gb[e] = 0.f; }
-    float bv[VEC], rdv[VEC];                // recon: bias and 1 / d of the lane's channels
+    float bv[VEC], rdv[VEC];                // XM == 2: bias and 1 / d of the lane's channels
     #pragma unroll
     for (int e = 0; e < VEC; e++) { bv[e] = 0.f; rdv[e] = 1.f; }
-    const float rstr = (p.recon && p.strength) ? *p.strength : 1.f;
+    const float rstr = (XM == 2 && p.strength) ? *p.strength : 1.f;
     const float rgain = 1.f / p.gain, ralpha = (A == 3 && p.alpha != 0.f) ? 1.f / p.alpha : 0.f;
-    if (p.recon) {
+    if (XM == 2) {
         if (p.bias) {
             const V b16 = *(const V*)(p.bias + cvi * VEC);
             #pragma unroll
@@ -476,44 +528,14 @@ __global__ void __launch_bounds__(256) bwd_fused_nhwc_kernel(BnArgs<T> p)
         for (int e = 0; e < VEC; e++) rdv[e] = 1.f / dv[e];
     }
     constexpr int BU = 4;
-    for (uint32_t pix0 = lo + pl; pix0 < hi; pix0 += ppi * BU) {
-        V vdy[BU], vy[BU], vx[BU];
-        float nz[BU];
-        #pragma unroll
-        for (int u = 0; u < BU; u++) {
-            const uint32_t pix = pix0 + u * ppi;
-            if (pix >= hi) continue;
-            const size_t off = base + (size_t)pix * p.c;
-            vdy[u] = *(const V*)(p.dy + off);
-            if (p.yref) vy[u] = *(const V*)(p.yref + off);
-            if (p.x) vx[u] = *(const V*)(p.x + off);
-            nz[u] = nzp ? nzp[pix] : 0.f;
-        }
-        #pragma unroll
-        for (int u = 0; u < BU; u++) {
-            const uint32_t pix = pix0 + u * ppi;
-            if (pix >= hi) continue;
-            V out;
-            float srow = 0.f;
-            #pragma unroll
-            for (int e = 0; e < VEC; e++) {
-                float g = to_acc<T>(vdy[u].v[e]);
-                if (p.yref) g = ba_eval<float, A>(1, g, 0.f, 0.f, to_acc<T>(vy[u].v[e]), 1.f, k);
-                const float gq = to_acc<T>(from_acc<T>(g));        // autograd materialises dpre in T
-                out.v[e] = from_acc<T>(gq * dv[e]);
-                s_gb[e] += gq;
-                if (p.x) s_gd[e] += gq * to_acc<T>(vx[u].v[e]);
-                else if (p.recon) {
-                    float pre = to_acc<T>(vy[u].v[e]) * rgain;
-                    if (A == 3 && pre < 0.f) pre *= ralpha;
-                    s_gd[e] += gq * ((pre - nz[u] * rstr - bv[e]) * rdv[e]);
-                }
-                srow += gq;
-            }
-            if (nzp) s_gs += srow * nz[u];
-            *(V*)(p.dx + base + (size_t)pix * p.c) = out;
-        }
-    }
+    uint32_t pix0 = lo + pl;
+    // (slice_pix is a multiple of ppi * BU: inside a whole slice every lane of every round has a pixel)
+    if (lo + p.slice_pix <= p.hw)
+        for (; pix0 < hi; pix0 += ppi * BU)
+            bn_round<T, A, YREF, XM, NZ, true, BU>(p, k, base, pix0, ppi, hi, nzp, dv, bv, rdv, rstr, rgain, ralpha, s_gd, s_gb, s_gs);
+    else
+        for (; pix0 < hi; pix0 += ppi * BU)
+            bn_round<T, A, YREF, XM, NZ, false, BU>(p, k, base, pix0, ppi, hi, nzp, dv, bv, rdv, rstr, rgain, ralpha, s_gd, s_gb, s_gs);
     __shared__ float red[256][VEC + 1];
     const uint32_t C = p.c;
     if (p.gd) {
@@ -539,7 +561,7 @@ __global__ void __launch_bounds__(256) bwd_fused_nhwc_kernel(BnArgs<T> p)
             atomicAdd(p.gb + (size_t)n * C + ch, t);
         }
     }
-    if (p.gs) {
+    if (NZ && p.gs) {
         #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s_gs += __shfl_down(s_gs, o, 64);
         __shared__ float red_s[4];
@@ -547,6 +569,13 @@ __global__ void __launch_bounds__(256) bwd_fused_nhwc_kernel(BnArgs<T> p)
         __syncthreads();
         if (threadIdx.x == 0) atomicAdd(p.gs + (blockIdx.x % MG_GS_SLOTS), red_s[0] + red_s[1] + red_s[2] + red_s[3]);
     }
+}
+
+template <class T, int A, int YREF, int XM>
+void launch_bn(const BnArgs<T>& b, uint32_t n, hipStream_t s)
+{
+    if (b.noise) hipLaunchKernelGGL((bwd_fused_nhwc_kernel<T, A, YREF, XM, 1>), dim3(n * b.slices), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((bwd_fused_nhwc_kernel<T, A, YREF, XM, 0>), dim3(n * b.slices), dim3(256), 0, s, b);
 }
 
 template <class T, int A>
@@ -557,7 +586,16 @@ void launch_nhwc(const FnArgs<T>* f, const BnArgs<T>* b, uint32_t n, hipStream_t
         if (blocks > 256u * 8u) blocks = 256u * 8u;
         hipLaunchKernelGGL((fma_bias_act_nhwc_fwd_kernel<T, A>), dim3(blocks), dim3(256), 0, s, *f);
     } else {
-        hipLaunchKernelGGL((bwd_fused_nhwc_kernel<T, A>), dim3(n * b->slices), dim3(256), 0, s, *b);
+        // what the launch reads, as template arguments (the entry point checked: recon implies yref and no x)
+        const int xm = b->recon ? 2 : (b->x ? 1 : 0);
+        if (b->yref) {
+            if (xm == 2) launch_bn<T, A, 1, 2>(*b, n, s);
+            else if (xm == 1) launch_bn<T, A, 1, 1>(*b, n, s);
+            else launch_bn<T, A, 1, 0>(*b, n, s);
+        } else {
+            if (xm == 1) launch_bn<T, A, 0, 1>(*b, n, s);
+            else launch_bn<T, A, 0, 0>(*b, n, s);
+        }
     }
 }
 

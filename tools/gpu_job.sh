@@ -1,7 +1,5 @@
 #!/bin/bash
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd $R
-for cfg in "A=1" "MG_WGRAD=0" "MG_WGRAD=0 MG_BLUR_EPILOGUE=0" "MG_WGRAD=0 MG_MODCONV=0" "A=2"; do
-  echo "== $cfg"
-  env $cfg timeout -k 10 300 python -m pytest tests/test_train_step_gpu.py -q -m gpu -k "recorded_phases_equal" -s 2>&1 | grep -E "recorded-vs-eager|passed|failed" | cut -c1-200
-done
+timeout -k 10 200 python tools/bench_bwd_fused.py > gpurun_out/r3_bwd_fused_bench.log 2>&1; echo rc=$?; tail -14 gpurun_out/r3_bwd_fused_bench.log
+timeout -k 10 400 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "fused or epilogue or nhwc" > gpurun_out/wg_tests.log 2>&1; echo rc=$?; tail -5 gpurun_out/wg_tests.log | cut -c1-220
