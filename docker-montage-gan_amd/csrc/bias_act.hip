@@ -32,11 +32,63 @@ template <class T> __device__ __forceinline__ uint32_t ba_bias_index(uint32_t i,
 // GT: gradient order known at compile time (0 or 1; -1 = read p.grad).  With GT fixed the loads that
 // order never needs (xref/yref/dy at order 0; b/xref/dy for the 'y'-referenced activations at order 1)
 // and their null checks disappear from the per-element code.
+// One chunk of 256 * U vectors.  FULL: every lane of every access is inside the tensor (no bounds test); HXR / HY / HDY: which
+// of the saved tensors this launch reads -- compile-time, so the chunk's loads issue back to back (tested at run time, each
+// load sat in its own basic block behind `s_waitcnt vmcnt(0)`).
+template <class T, int A, int VEC, int U, int BVEC, bool FULL, int RXR, int RY, int RDY, class P, class K>
+__device__ __forceinline__ void ba_chunk(const P& p, const K& k, int G, uint32_t base, uint32_t nvec)
+{
+    typedef typename Acc<T>::type acc_t;
+    struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
+    // 0 / 1: known at compile time; 2: whatever the pointer says (the generic instantiations)
+    const bool HXR = RXR == 2 ? p.xref != nullptr : RXR != 0, HY = RY == 2 ? p.yref != nullptr : RY != 0, HDY = RDY == 2 ? p.dy != nullptr : RDY != 0;
+    V vx[U], vxr[U], vyr[U], vdy[U];
+    #pragma unroll
+    for (int u = 0; u < U; u++) {
+        uint32_t vi = base + u * 256u + threadIdx.x;
+        if (FULL || vi < nvec) {
+            vx[u] = ((const V*)p.x)[vi];
+            if (HXR) vxr[u] = ((const V*)p.xref)[vi];
+            if (HY) vyr[u] = ((const V*)p.yref)[vi];
+            if (HDY) vdy[u] = ((const V*)p.dy)[vi];
+        }
+    }
+    #pragma unroll
+    for (int u = 0; u < U; u++) {
+        uint32_t vi = base + u * 256u + threadIdx.x;
+        if (!FULL && vi >= nvec) continue;
+        acc_t bv = 0;
+        V bvec;
+        if (BVEC == 1 && p.b) bv = to_acc<T>(p.b[ba_bias_index(vi * VEC, p)]);
+        if (BVEC == 2 && p.b) bvec = *(const V*)(p.b + ba_bias_index(vi * VEC, p));
+        V out;
+        #pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            if (BVEC == 0 && p.b) bv = to_acc<T>(p.b[ba_bias_index(vi * VEC + e, p)]);
+            if (BVEC == 2 && p.b) bv = to_acc<T>(bvec.v[e]);
+            acc_t xr = HXR ? to_acc<T>(vxr[u].v[e]) : (acc_t)0;
+            acc_t yr = HY ? to_acc<T>(vyr[u].v[e]) : (acc_t)0;
+            acc_t dy = HDY ? to_acc<T>(vdy[u].v[e]) : (acc_t)1;
+            out.v[e] = from_acc<T>(ba_eval<acc_t, A>(G, to_acc<T>(vx[u].v[e]), bv, xr, yr, dy, k));
+        }
+        ((V*)p.y)[vi] = out;
+    }
+}
+
+template <class T, int A, int VEC, int U, int BVEC, int GT, bool FULL, class P, class K>
+__device__ __forceinline__ void ba_chunk_by_reads(const P& p, const K& k, int G, uint32_t base, uint32_t nvec)
+{
+    if (GT == 0) ba_chunk<T, A, VEC, U, BVEC, FULL, 0, 0, 0>(p, k, G, base, nvec);
+    else if (GT == 1 && A <= 8) {
+        if (p.yref) ba_chunk<T, A, VEC, U, BVEC, FULL, 0, 1, 0>(p, k, G, base, nvec);       // (uniform)
+        else ba_chunk<T, A, VEC, U, BVEC, FULL, 0, 0, 0>(p, k, G, base, nvec);
+    } else ba_chunk<T, A, VEC, U, BVEC, FULL, 2, 2, 2>(p, k, G, base, nvec);
+}
+
 template <class T, int A, int VEC, int U, int BVEC, int GT>
 __global__ void __launch_bounds__(256) bias_act_kernel(BaArgs<T> p0)
 {
     typedef typename Acc<T>::type acc_t;
-    struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
     BaArgs<T> p = p0;
     if (GT == 0) { p.xref = nullptr; p.yref = nullptr; p.dy = nullptr; }
     if (GT == 1) { p.dy = nullptr; if (A <= 8) { p.xref = nullptr; p.b = nullptr; } }
@@ -45,37 +97,8 @@ __global__ void __launch_bounds__(256) bias_act_kernel(BaArgs<T> p0)
     const uint32_t nvec = p.size_x / VEC;
     const uint32_t chunk = 256u * U;
     for (uint32_t base = blockIdx.x * chunk; base < nvec; base += gridDim.x * chunk) {
-        V vx[U], vxr[U], vyr[U], vdy[U];
-        #pragma unroll
-        for (int u = 0; u < U; u++) {
-            uint32_t vi = base + u * 256u + threadIdx.x;
-            if (vi < nvec) {
-                vx[u] = ((const V*)p.x)[vi];
-                if (p.xref) vxr[u] = ((const V*)p.xref)[vi];
-                if (p.yref) vyr[u] = ((const V*)p.yref)[vi];
-                if (p.dy)   vdy[u] = ((const V*)p.dy)[vi];
-            }
-        }
-        #pragma unroll
-        for (int u = 0; u < U; u++) {
-            uint32_t vi = base + u * 256u + threadIdx.x;
-            if (vi >= nvec) continue;
-            acc_t bv = 0;
-            V bvec;
-            if (BVEC == 1 && p.b) bv = to_acc<T>(p.b[ba_bias_index(vi * VEC, p)]);
-            if (BVEC == 2 && p.b) bvec = *(const V*)(p.b + ba_bias_index(vi * VEC, p));
-            V out;
-            #pragma unroll
-            for (int e = 0; e < VEC; e++) {
-                if (BVEC == 0 && p.b) bv = to_acc<T>(p.b[ba_bias_index(vi * VEC + e, p)]);
-                if (BVEC == 2 && p.b) bv = to_acc<T>(bvec.v[e]);
-                acc_t xr = p.xref ? to_acc<T>(vxr[u].v[e]) : (acc_t)0;
-                acc_t yr = p.yref ? to_acc<T>(vyr[u].v[e]) : (acc_t)0;
-                acc_t dy = p.dy ? to_acc<T>(vdy[u].v[e]) : (acc_t)1;
-                out.v[e] = from_acc<T>(ba_eval<acc_t, A>(G, to_acc<T>(vx[u].v[e]), bv, xr, yr, dy, k));
-            }
-            ((V*)p.y)[vi] = out;
-        }
+        if (GT < 0 || base + chunk > nvec) ba_chunk_by_reads<T, A, VEC, U, BVEC, GT, false>(p, k, G, base, nvec);
+        else ba_chunk_by_reads<T, A, VEC, U, BVEC, GT, true>(p, k, G, base, nvec);
     }
     // tail (size_x not a multiple of VEC): last block, first lanes
     if (VEC > 1 && blockIdx.x == gridDim.x - 1) {

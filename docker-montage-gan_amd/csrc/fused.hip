@@ -374,51 +374,78 @@ template <class T> struct FnArgs {
     FastDiv cv_div, hw_div;
 };
 
-template <class T, int A>
-__global__ void __launch_bounds__(256) fma_bias_act_nhwc_fwd_kernel(FnArgs<T> p)
+// HD / HN / HB: dcoefs / noise / bias present -- compile-time, and FULL chunks carry no bounds test, so the FB_U activation
+// vectors of a chunk and their per-pixel noise samples are requested back to back (tested at run time, every load sat behind
+// its own branch and `s_waitcnt vmcnt(0)`).
+template <class T, int A, bool HD, bool HN, bool HB, bool FULL>
+__device__ __forceinline__ void fn_chunk(const FnArgs<T>& p, const BaConst<float>& k, float ngain, uint32_t base)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
     struct alignas(16) V { T v[VEC]; };
     typedef float f4_t __attribute__((ext_vector_type(4)));
-    const BaConst<float> k = {p.alpha, p.gain, p.clamp};
-    const float ngain = p.noise_gain * ((p.noise && p.noise_gain_dev) ? *p.noise_gain_dev : 1.f);
-    for (uint32_t base = blockIdx.x * (256u * FB_U); base < p.total_vec; base += gridDim.x * (256u * FB_U)) {
-        V xin[FB_U], bv[FB_U];
-        float dv[FB_U][VEC], nz[FB_U];
-        #pragma unroll
-        for (int u = 0; u < FB_U; u++) {
-            const uint32_t vi = base + u * 256u + threadIdx.x;
-            if (vi >= p.total_vec) continue;
-            xin[u] = ((const V*)p.x)[vi];
-            const uint32_t pixn = fd_div(vi, p.cv_div), cvi = vi - pixn * p.cv;
-            const uint32_t n = fd_div(pixn, p.hw_div), pix = pixn - n * p.hw;
-            nz[u] = p.noise ? p.noise[(int64_t)n * p.noise_stride_n + pix] : 0.f;
-            if (p.b) bv[u] = *(const V*)(p.b + cvi * VEC);
-            if (p.d) {
-                const f4_t* dp = (const f4_t*)(p.d + (size_t)n * p.c + cvi * VEC);
-                #pragma unroll
-                for (int q = 0; q < VEC / 4; q++) {
-                    const f4_t t = dp[q];
-                    dv[u][4 * q] = t.x; dv[u][4 * q + 1] = t.y; dv[u][4 * q + 2] = t.z; dv[u][4 * q + 3] = t.w;
-                }
-                #pragma unroll
-                for (int e = 0; e < VEC; e++) dv[u][e] = to_acc<T>(from_acc<T>(dv[u][e]));       // dcoefs.to(x.dtype)
-            }
-        }
-        #pragma unroll
-        for (int u = 0; u < FB_U; u++) {
-            const uint32_t vi = base + u * 256u + threadIdx.x;
-            if (vi >= p.total_vec) continue;
-            V out;
+    V xin[FB_U], bv[FB_U];
+    f4_t dq[FB_U][VEC / 4];
+    float nz[FB_U];
+    #pragma unroll
+    for (int u = 0; u < FB_U; u++) {
+        const uint32_t vi = base + u * 256u + threadIdx.x;
+        if (!FULL && vi >= p.total_vec) continue;
+        xin[u] = ((const V*)p.x)[vi];
+        const uint32_t pixn = fd_div(vi, p.cv_div), cvi = vi - pixn * p.cv;
+        const uint32_t n = fd_div(pixn, p.hw_div), pix = pixn - n * p.hw;
+        nz[u] = HN ? p.noise[(int64_t)n * p.noise_stride_n + pix] : 0.f;
+        if (HB) bv[u] = *(const V*)(p.b + cvi * VEC);
+        if (HD) {
+            const f4_t* dp = (const f4_t*)(p.d + (size_t)n * p.c + cvi * VEC);
             #pragma unroll
-            for (int e = 0; e < VEC; e++) {
-                float v = to_acc<T>(xin[u].v[e]) * (p.d ? dv[u][e] : 1.f);
-                if (p.noise) v = __builtin_fmaf(nz[u], ngain, v);
-                v = to_acc<T>(from_acc<T>(v));                      // the reference rounds the fma result to T
-                out.v[e] = from_acc<T>(ba_eval<float, A>(0, v, p.b ? (float)to_acc<T>(bv[u].v[e]) : 0.f, 0.f, 0.f, 1.f, k));
-            }
-            ((V*)p.y)[vi] = out;
+            for (int q = 0; q < VEC / 4; q++) dq[u][q] = dp[q];
         }
+    }
+    #pragma unroll
+    for (int u = 0; u < FB_U; u++) {
+        const uint32_t vi = base + u * 256u + threadIdx.x;
+        if (!FULL && vi >= p.total_vec) continue;
+        V out;
+        #pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const float de = HD ? (float)to_acc<T>(from_acc<T>(dq[u][e / 4][e % 4])) : 1.f;       // dcoefs.to(x.dtype)
+            float v = to_acc<T>(xin[u].v[e]) * de;
+            if (HN) v = __builtin_fmaf(nz[u], ngain, v);
+            // (a float32 value of its own, as in the NCHW kernel, whose run-time noise test keeps the pieces apart: with HN known
+            // the compiler would contract a float32 product with the bias add inside ba_eval into one fma, and fuse the float16
+            // rounding below into the fma -- v_fma_mixlo_f16, ONE rounding where the NCHW kernel and the reference round twice)
+            asm volatile("" : "+v"(v));
+            v = to_acc<T>(from_acc<T>(v));                      // the reference rounds the fma result to T
+            out.v[e] = from_acc<T>(ba_eval<float, A>(0, v, HB ? (float)to_acc<T>(bv[u].v[e]) : 0.f, 0.f, 0.f, 1.f, k));
+        }
+        ((V*)p.y)[vi] = out;
+    }
+}
+
+template <class T, int A, bool HD, bool HN, bool HB>
+__global__ void __launch_bounds__(256) fma_bias_act_nhwc_fwd_kernel(FnArgs<T> p)
+{
+    const BaConst<float> k = {p.alpha, p.gain, p.clamp};
+    const float ngain = p.noise_gain * ((HN && p.noise_gain_dev) ? *p.noise_gain_dev : 1.f);
+    for (uint32_t base = blockIdx.x * (256u * FB_U); base < p.total_vec; base += gridDim.x * (256u * FB_U)) {
+        if (base + 256u * FB_U <= p.total_vec) fn_chunk<T, A, HD, HN, HB, true>(p, k, ngain, base);
+        else fn_chunk<T, A, HD, HN, HB, false>(p, k, ngain, base);
+    }
+}
+
+template <class T, int A>
+void launch_fn(const FnArgs<T>& f, uint32_t blocks, hipStream_t s)
+{
+    const int key = (f.d ? 4 : 0) | (f.noise ? 2 : 0) | (f.b ? 1 : 0);
+    switch (key) {
+    case 0: hipLaunchKernelGGL((fma_bias_act_nhwc_fwd_kernel<T, A, false, false, false>), dim3(blocks), dim3(256), 0, s, f); break;
+    case 1: hipLaunchKernelGGL((fma_bias_act_nhwc_fwd_kernel<T, A, false, false, true>), dim3(blocks), dim3(256), 0, s, f); break;
+    case 2: hipLaunchKernelGGL((fma_bias_act_nhwc_fwd_kernel<T, A, false, true, false>), dim3(blocks), dim3(256), 0, s, f); break;
+    case 3: hipLaunchKernelGGL((fma_bias_act_nhwc_fwd_kernel<T, A, false, true, true>), dim3(blocks), dim3(256), 0, s, f); break;
+    case 4: hipLaunchKernelGGL((fma_bias_act_nhwc_fwd_kernel<T, A, true, false, false>), dim3(blocks), dim3(256), 0, s, f); break;
+    case 5: hipLaunchKernelGGL((fma_bias_act_nhwc_fwd_kernel<T, A, true, false, true>), dim3(blocks), dim3(256), 0, s, f); break;
+    case 6: hipLaunchKernelGGL((fma_bias_act_nhwc_fwd_kernel<T, A, true, true, false>), dim3(blocks), dim3(256), 0, s, f); break;
+    default: hipLaunchKernelGGL((fma_bias_act_nhwc_fwd_kernel<T, A, true, true, true>), dim3(blocks), dim3(256), 0, s, f); break;
     }
 }
 
@@ -584,7 +611,7 @@ void launch_nhwc(const FnArgs<T>* f, const BnArgs<T>* b, uint32_t n, hipStream_t
     if (f) {
         uint32_t blocks = (f->total_vec + 256u * FB_U - 1) / (256u * FB_U);
         if (blocks > 256u * 8u) blocks = 256u * 8u;
-        hipLaunchKernelGGL((fma_bias_act_nhwc_fwd_kernel<T, A>), dim3(blocks), dim3(256), 0, s, *f);
+        launch_fn<T, A>(*f, blocks, s);
     } else {
         // what the launch reads, as template arguments (the entry point checked: recon implies yref and no x)
         const int xm = b->recon ? 2 : (b->x ? 1 : 0);

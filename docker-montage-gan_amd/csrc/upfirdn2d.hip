@@ -34,13 +34,44 @@ struct UfParams {
 // EPI = 0: none; 1 / 3: epilogue with the linear / leaky-ReLU activation
 template <class T, int EPI, int VEC> struct UfEpiLane {
     float d[VEC], b[VEC], st;
+    // The noise plane behind a buffer descriptor: a lane without a sample (no noise at all, or a pixel outside the output)
+    // asks for NZ_BAD and gets 0 back, so the request can be issued early and unconditionally, next to the input rows it
+    // travels with (tested at run time in the store loop, the load sat behind `s_waitcnt vmcnt(0)` and the wait drained
+    // the prefetched input rows with it).
+    static constexpr unsigned NZ_BAD = 0x80000000u;
+    __device__ __forceinline__ static __amdgpu_buffer_rsrc_t noise_rsrc(const UfParams& p)
+    {
+        const int64_t bytes = p.ep_noise ? ((int64_t)(p.n - 1) * p.ep_noise_stride_n + (int64_t)p.out_h * p.out_w) * 4 : 0;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ep_noise ? p.ep_noise : p.f), 0, (int)bytes, 0x00020000);
+    }
+    __device__ __forceinline__ static float noise_at(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
+    {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+    }
     __device__ __forceinline__ void init(const UfParams& p, uint32_t n, uint32_t cvi)
     {
         if (EPI == 0) return;
+        // the lane's channel vector of dcoefs and bias as 16-byte loads behind ONE test each (element by element, each load
+        // sat behind its own test and `s_waitcnt vmcnt(0)`: 2 * VEC serialised round trips before the first input row)
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        struct alignas(16) V { T v[VEC]; };
         #pragma unroll
-        for (int e = 0; e < VEC; e++) {
-            d[e] = p.ep_d ? (float)to_acc<T>(from_acc<T>(p.ep_d[(size_t)n * p.c + cvi * VEC + e])) : 1.f;
-            b[e] = p.ep_b ? (float)to_acc<T>(((const T*)p.ep_b)[cvi * VEC + e]) : 0.f;
+        for (int e = 0; e < VEC; e++) { d[e] = 1.f; b[e] = 0.f; }
+        if (p.ep_d) {
+            const f4_t* dp = (const f4_t*)(p.ep_d + (size_t)n * p.c + cvi * VEC);
+            f4_t q[VEC / 4];
+            #pragma unroll
+            for (int h = 0; h < VEC / 4; h++) q[h] = dp[h];
+            #pragma unroll
+            for (int h = 0; h < VEC / 4; h++) {
+                d[4 * h] = to_acc<T>(from_acc<T>(q[h].x)); d[4 * h + 1] = to_acc<T>(from_acc<T>(q[h].y));
+                d[4 * h + 2] = to_acc<T>(from_acc<T>(q[h].z)); d[4 * h + 3] = to_acc<T>(from_acc<T>(q[h].w));
+            }
+        }
+        if (p.ep_b) {
+            const V bq = *(const V*)((const T*)p.ep_b + cvi * VEC);
+            #pragma unroll
+            for (int e = 0; e < VEC; e++) b[e] = to_acc<T>(bq.v[e]);
         }
         st = (p.ep_noise && p.ep_strength) ? *p.ep_strength : 1.f;
     }
@@ -49,10 +80,11 @@ template <class T, int EPI, int VEC> struct UfEpiLane {
     {
         if (EPI == 0) return;
         const BaConst<float> k = {p.ep_alpha, p.ep_gain, p.ep_clamp};
+        const bool has_nz = p.ep_noise != nullptr;
         #pragma unroll
         for (int e = 0; e < VEC; e++) {
             float t = (float)to_acc<T>(from_acc<T>(v[e])) * d[e];           // the filter's output is a T tensor
-            if (p.ep_noise) t = __builtin_fmaf(nz, st, t);
+            t = has_nz ? __builtin_fmaf(nz, st, t) : t;                     // (a select, not a branch)
             t = (float)to_acc<T>(from_acc<T>(t));
             v[e] = ba_eval<float, (EPI == 0 ? 1 : EPI)>(0, t, b[e], 0.f, 0.f, 1.f, k);
         }
@@ -589,6 +621,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
 
     UfEpiLane<T, EPI, VEC> epi;
     epi.init(p, n, cvi);
+    const auto rnz = UfEpiLane<T, EPI, VEC>::noise_rsrc(p);
     const int pix_bytes = p.c * ES;
     const int ox0 = (int)gxi * MX;
     const int ix0 = mg_floor_div(UP - 1 - p.padx0, UP) + (int)gxi * LANE_DX;        // first input column of the lane window
@@ -615,6 +648,17 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
                 #pragma unroll
                 for (int e = 0; e < VEC / 2; e++) acc[j][i][e] = (f2_t){0.f, 0.f};
 
+        float nzv[MY][MX];
+        if (EPI) {
+            #pragma unroll
+            for (int j = 0; j < MY; j++)
+                #pragma unroll
+                for (int i = 0; i < MX; i++) {
+                    const int oy = oy0 + j;
+                    const bool in = oy < p.out_h && ox0 + i < p.out_w;
+                    nzv[j][i] = epi.noise_at(rnz, in ? (unsigned)(((int64_t)n * p.ep_noise_stride_n + (int64_t)oy * p.out_w + ox0 + i) * 4) : epi.NZ_BAD);
+                }
+        }
         // rows are requested RG at a time (at most 16 vectors = 64 VGPRs in flight), then consumed
         constexpr int RG = (RX * RY <= 16) ? RY : (16 / RX);
         #pragma unroll
@@ -673,9 +717,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
                     float t[VEC];
                     #pragma unroll
                     for (int h = 0; h < VEC / 2; h++) { t[2 * h] = acc[j][i][h].x; t[2 * h + 1] = acc[j][i][h].y; }
-                    const bool in = oy < p.out_h && ox0 + i < p.out_w;
-                    const float nz = (p.ep_noise && in) ? p.ep_noise[(int64_t)n * p.ep_noise_stride_n + (int64_t)oy * p.out_w + ox0 + i] : 0.f;
-                    epi.apply(p, t, nz);
+                    epi.apply(p, t, nzv[j][i]);
                     __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack<T>(t), rout, off, 0, 0);
                 } else {
                     __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack2<T>(acc[j][i]), rout, off, 0, 0);
@@ -720,6 +762,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UfParams p, NhwcGrid 
 
     UfEpiLane<T, EPI, VEC> epi;
     epi.init(p, n, cvi);
+    const auto rnz = UfEpiLane<T, EPI, VEC>::noise_rsrc(p);
     const int pix_bytes = p.c * ES;
     const int ox = (int)gxi, ix0 = ox - p.padx0;
     int col_off[FW];
@@ -752,14 +795,21 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UfParams p, NhwcGrid 
         #pragma unroll
         for (int e = 0; e < VEC / 2; e++) acc[a][e] = (f2_t){0.f, 0.f};
 
+    // noise of output row `orow` of this lane's column (0 for rows in front of the chunk: they are never stored)
+    const unsigned nz_base = (unsigned)(((int64_t)n * p.ep_noise_stride_n + ox) * 4), nz_pitch = (unsigned)(p.out_w * 4);
+    auto load_noise = [&](int orow) -> float {
+        if (!EPI) return 0.f;
+        return UfEpiLane<T, EPI, VEC>::noise_at(rnz, (orow >= oy_begin && orow < p.out_h) ? nz_base + (unsigned)orow * nz_pitch : UfEpiLane<T, EPI, VEC>::NZ_BAD);
+    };
     u32x4_t cur[FW], nxt[FW];
     load_row(cur);
+    float nz_cur = load_noise(oy_begin - (FH - 1)), nz_nxt = 0.f;
     for (int jb = 0; jb < rows_in; jb += FH) {
         #pragma unroll
         for (int r = 0; r < FH; r++) {
             const int j = jb + r;
             if (j >= rows_in) break;
-            if (j + 1 < rows_in) load_row(nxt);
+            if (j + 1 < rows_in) { load_row(nxt); nz_nxt = load_noise(oy_begin + j + 1 - (FH - 1)); }
             f2_t row[FW][VEC / 2];
             #pragma unroll
             for (int kx = 0; kx < FW; kx++) nhwc_unpack2<T>(cur[kx], row[kx]);
@@ -779,9 +829,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UfParams p, NhwcGrid 
                     float t[VEC];
                     #pragma unroll
                     for (int h = 0; h < VEC / 2; h++) { t[2 * h] = acc[done][h].x; t[2 * h + 1] = acc[done][h].y; }
-                    const int oy = oy_begin + j - (FH - 1);
-                    const float nz = p.ep_noise ? p.ep_noise[(int64_t)n * p.ep_noise_stride_n + (int64_t)oy * p.out_w + ox] : 0.f;
-                    epi.apply(p, t, nz);
+                    epi.apply(p, t, nz_cur);
                     __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack<T>(t), rout, out_row_off + st_off, 0, 0);
                 } else {
                     __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack2<T>(acc[done]), rout, out_row_off + st_off, 0, 0);
@@ -792,6 +840,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UfParams p, NhwcGrid 
             for (int e = 0; e < VEC / 2; e++) acc[done][e] = (f2_t){0.f, 0.f};
             #pragma unroll
             for (int kx = 0; kx < FW; kx++) cur[kx] = nxt[kx];
+            nz_cur = nz_nxt;
         }
     }
 }
@@ -958,7 +1007,7 @@ extern "C" int mg_upfirdn2d_epilogue(const void* x, const float* f, void* y, int
     MG_REQUIRE(f_size[0] >= 1 && f_size[1] >= 1 && f_size[0] <= 4 && f_size[1] <= 4, "upfirdn2d_epilogue: filters of at most 4x4 taps");
     MG_REQUIRE(x_size[0] == y_size[0] && x_size[1] == y_size[1] && y_size[2] >= 1 && y_size[3] >= 1, "x and y must agree in batch and channels");
     const int64_t C = x_size[1];
-    MG_REQUIRE(C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)b) & 15) == 0, "upfirdn2d_epilogue: channels must be a multiple of 8, pointers 16-byte aligned");
+    MG_REQUIRE(C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)b | (uintptr_t)d) & 15) == 0, "upfirdn2d_epilogue: channels must be a multiple of 8, pointers 16-byte aligned");
     int64_t xn = (int64_t)x_size[0] * C * x_size[2] * x_size[3], yn = (int64_t)y_size[0] * C * y_size[2] * y_size[3];
     const int64_t lim = (1ll << 31) - 64;
     MG_REQUIRE(xn * 2 < lim && yn * 2 < lim && (int64_t)y_size[0] * ((y_size[2] + 31) / 32) * y_size[3] * (C / 8) < (int64_t)UINT32_MAX / 2, "x is too large");

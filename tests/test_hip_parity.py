@@ -1324,7 +1324,10 @@ def test_fused_modconv3x3_values_and_gradients(native, modconv_on, with_mod):
     x, wt, s, d, nz, st, b = _modconv_inputs(n, h, w, False, 11, with_mod)
     bb = b if with_mod else b.to(torch.bfloat16)
     names = ['x', 'w'] + (['s', 'd', 'st', 'b'] if with_mod else ['b'])
-    dy = torch.randn([n, 64, h, w], device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn([n, 64, h, w], device=DEV, generator=torch.Generator(device=DEV).manual_seed(12)).to(torch.bfloat16) \
+        .contiguous(memory_format=torch.channels_last)            # (its own generator: the same values whichever tests ran before)
+    # the natural size of the noise-strength gradient, ONE number sum_px dpre * noise of zero-mean terms: (sum of squared terms)^0.5
+    st_scale = float(dy.float().square().sum().sqrt()) * float(np.sqrt(2))
 
     def run(fused, second):
         leaves = [t.clone().requires_grad_(True) for t in ([x, wt] + ([s, d, st, bb] if with_mod else [bb]))]
@@ -1348,11 +1351,15 @@ def test_fused_modconv3x3_values_and_gradients(native, modconv_on, with_mod):
             scale = float(r.float().abs().max()) + 1e-6
             err = float((a.float() - r.float()).abs().max())
             name = names[i - 1] if (not second and i) else ''
-            # the noise-strength gradient is ONE number, sum_px dpre * noise: ~N^0.5 large with ~0.5 % of its N terms flipped
-            bound = 3e-2 if (i == 0 and not second) else 0.2
+            # the noise-strength gradient: ~0.5 % of its N terms flip by a leaky-ReLU slope, a random sum of ~(0.005 N)^0.5 of them;
+            # its own value can be anything down to 0, so the error is held against the natural size of the sum instead
+            # (measured: 0.02-0.05 of it)
+            if name == 'st':
+                scale = st_scale
+            bound = 3e-2 if (i == 0 and not second) else 0.1 if name == 'st' else 0.2
             assert err <= bound * scale, (second, i, names[i - 1] if (not second and i) else i, err, scale)
             mean = float((a.float() - r.float()).abs().mean())
-            assert mean <= (4e-3 if (i == 0 and not second) else 0.2 if name == 'st' else 1.5e-2) * scale, (second, i, name, mean, scale)
+            assert mean <= (4e-3 if (i == 0 and not second) else 0.1 if name == 'st' else 1.5e-2) * scale, (second, i, name, mean, scale)
 
 
 @pytest.mark.parametrize('shape', [(2, 4, 32), (3, 16, 64), (1, 64, 96), (2, 256, 256)])
