@@ -855,7 +855,11 @@ void launch_nhwc_phase(const UfParams& p, hipStream_t s)
     g.cv = (uint32_t)(p.c / VEC);
     g.gx = (uint32_t)((p.out_w + MX - 1) / MX);
     // rows per chunk: a multiple of MY; 32 output rows keep the inter-chunk halo small while leaving >= 8 workgroups per CU on the big layers
-    g.rows_per_chunk = 32;
+    // (row streaming from 96 rows up: 16-row chunks at 128^2 re-read 3 rows in 16 where the block kernel re-reads 3 in 4)
+    // (with the epilogue on the way out the block kernel stays ahead below 192 rows: 91 against 103 us at [32,128,128,128])
+    const bool epi = UP == 1 && DN == 1 && sizeof(T) == 2 && (g_epi_act == 1 || g_epi_act == 3);
+    const bool stream_rows = UP == 1 && DN == 1 && p.out_h >= (epi ? 192 : 96);
+    g.rows_per_chunk = (stream_rows && p.out_h < 192) ? 16 : 32;
     g.nchunks = (uint32_t)((p.out_h + (int)g.rows_per_chunk - 1) / (int)g.rows_per_chunk);
     g.total = (uint32_t)p.n * g.nchunks * g.gx * g.cv;
     g.cv_div = make_fastdiv(g.cv); g.gx_div = make_fastdiv(g.gx); g.chunk_div = make_fastdiv(g.nchunks);
@@ -863,13 +867,13 @@ void launch_nhwc_phase(const UfParams& p, hipStream_t s)
     const dim3 grid((g.total + 255u) / 256u);
     if constexpr (UP == 1 && DN == 1 && sizeof(T) == 2) {
         if (g_epi_act == 1 || g_epi_act == 3) {      // mg_upfirdn2d_epilogue: same kernels, epilogue on the way out
-            const bool rows = p.out_h >= 192;
+            const bool rows = stream_rows;
             if (g_epi_act == 3) { if (rows) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, 3>), grid, dim3(256), 0, s, p, g); else hipLaunchKernelGGL((upfirdn2d_nhwc<T, 1, 1, 0, 0, MX, MY, 3>), grid, dim3(256), 0, s, p, g); }
             else                { if (rows) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T, 1>), grid, dim3(256), 0, s, p, g); else hipLaunchKernelGGL((upfirdn2d_nhwc<T, 1, 1, 0, 0, MX, MY, 1>), grid, dim3(256), 0, s, p, g); }
             return;
         }
     }
-    if (UP == 1 && DN == 1 && p.out_h >= 192) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T>), grid, dim3(256), 0, s, p, g);
+    if (stream_rows) hipLaunchKernelGGL((upfirdn2d_nhwc_rows<T>), grid, dim3(256), 0, s, p, g);
     else hipLaunchKernelGGL((upfirdn2d_nhwc<T, UP, DN, PX, PY, MX, MY>), grid, dim3(256), 0, s, p, g);
 }
 
