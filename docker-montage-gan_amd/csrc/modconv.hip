@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) modconv3x3_c64_kernel(McArgs p)
     auto issue_piece = [&](int t, int buf, int i) {
         const int q = wave + 4 * i;
         if (q >= MC_PIECES) return;                                     // (wave-uniform)
-        const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+        const int tx = t / p.tiles_y, ty = t - tx * p.tiles_y;       // column-major walk: consecutive tiles share halo rows (L2)
         const int y0 = ty * MC_TH - 1, x0 = tx * MC_TW - 1;
         uint32_t lv = (uint32_t)lane;
         asm volatile("" : "+v"(lv));
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256, 2) modconv3x3_c64_kernel(McArgs p)
     if (tid < MC_C) dl[tid] = p.d ? rbf(p.d[(size_t)n * MC_C + tid]) : 1.f;     // dcoefs.to(x.dtype)
     float nz_next[2] = {0.f, 0.f};
     if (p.noise && p.y) {
-        const int ty0 = t_begin / p.tiles_x, tx0 = t_begin - ty0 * p.tiles_x;
+        const int tx0 = t_begin / p.tiles_y, ty0 = t_begin - tx0 * p.tiles_y;
         #pragma unroll
         for (int pb = 0; pb < 2; pb++)
             nz_next[pb] = p.noise[(size_t)n * p.noise_stride_n + (size_t)(ty0 * MC_TH + rh * 2 + pb) * p.w_ + tx0 * MC_TW + r];
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256, 2) modconv3x3_c64_kernel(McArgs p)
     if (DBG) tc = __builtin_readcyclecounter();
     for (int t = t_begin; t < t_end; t++) {
         const int buf = (t - t_begin) & 1;
-        const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+        const int tx = t / p.tiles_y, ty = t - tx * p.tiles_y;       // column-major walk: consecutive tiles share halo rows (L2)
         const int oy0 = ty * MC_TH, ox0 = tx * MC_TW;
 
         MC_MARK(0);
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) modconv3x3_c64_kernel(McArgs p)
         float nzv[2] = {nz_next[0], nz_next[1]};
         if (t + 1 < t_end) {
             if (p.noise && p.y) {
-                const int ty1 = (t + 1) / p.tiles_x, tx1 = (t + 1) - ty1 * p.tiles_x;
+                const int tx1 = (t + 1) / p.tiles_y, ty1 = (t + 1) - tx1 * p.tiles_y;
                 #pragma unroll
                 for (int pb = 0; pb < 2; pb++)
                     nz_next[pb] = p.noise[(size_t)n * p.noise_stride_n + (size_t)(ty1 * MC_TH + rh * 2 + pb) * p.w_ + tx1 * MC_TW + r];

@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256, 2) wgrad3x3_c64_kernel(WgArgs p)
         for (int e = 0; e < 16; e++) acc[t][e] = 0.f;
 
     for (int t = t_begin; t < t_end; t++) {
-        const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+        const int tx = t / p.tiles_y, ty = t - tx * p.tiles_y;       // column-major walk: consecutive tiles share halo rows (L2)
         const int y0 = ty * WG_TH, x0 = tx * WG_TW;
         __syncthreads();                        // every wave is done reading the previous tile's images
         {

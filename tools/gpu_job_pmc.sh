@@ -1,8 +1,8 @@
 #!/bin/bash
 # FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes (kernel-trace only), as MI355X_MICROARCH.md prescribes
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_pmc; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03_pmc; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for cfg in "ada_up float32" "ada_down float32" "demod float32 nchw" "demod float32 nhwc" "modconv bfloat16" "bwd_fused bfloat16 nhwc"; do
+for cfg in "upfirdn2d bfloat16 nhwc" "upfirdn2d128 bfloat16 nhwc" "bwd_fused bfloat16 nhwc" "epilogue bfloat16 nhwc" "wgrad bfloat16 nhwc" "torgb bfloat16 nhwc" "modconv bfloat16 nhwc" "bias_act bfloat16 nhwc"; do
   set -- $cfg; k=$1; dt=$2; lay=${3:-nchw}
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_run

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch ONE native kernel configuration a few times (for rocprofv3 --pmc runs).
-usage: kernel_loop.py <upfirdn2d|up2|down2|bias_act|calib4|epilogue|bwd_fused|ada_up|ada_down|demod|modconv> <dtype> [iters] [nchw|nhwc]"""
+usage: kernel_loop.py <upfirdn2d|upfirdn2d128|up2|down2|bias_act|calib4|epilogue|bwd_fused|ada_up|ada_down|demod|modconv|wgrad|torgb> <dtype> [iters] [nchw|nhwc]"""
 import importlib
 import os
 import sys
@@ -23,6 +23,23 @@ f = U.setup_filter([1, 3, 3, 1]).to(dev)
 if which == 'upfirdn2d':
     x = torch.randn([n, c, r + 1, r + 1], device=dev).to(dt).contiguous(memory_format=fmt)
     fn = lambda: U.upfirdn2d(x, f, padding=[1, 1, 1, 1], gain=4)
+elif which == 'upfirdn2d128':
+    c, r = 128, 128
+    x = torch.randn([n, c, r + 1, r + 1], device=dev).to(dt).contiguous(memory_format=fmt)
+    fn = lambda: U.upfirdn2d(x, f, padding=[1, 1, 1, 1], gain=4)
+elif which == 'wgrad':
+    M = importlib.import_module(f'{PKG}.torch_utils.ops.modconv3x3')
+    x = torch.randn([n, c, r, r], device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn_like(x)
+    w = (torch.randn([64, 64, 3, 3], device=dev) / 24).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    sst = torch.randn([n, c], device=dev) + 1
+    fn = lambda: M.wgrad3x3_c64(gy, x, sst, w)[0]
+elif which == 'torgb':
+    T = importlib.import_module(f'{PKG}.torch_utils.ops.torgb')
+    x = torch.randn([n, c, r, r], device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn([4, 64, 1, 1], device=dev) / 8).to(torch.bfloat16)
+    sst, b = torch.randn([n, c], device=dev) + 1, torch.randn([4], device=dev)
+    fn = lambda: T.torgb(x, w, sst, b, 256)
 elif which == 'bias_act':
     x = torch.randn([n, c, r, r], device=dev).to(dt).contiguous(memory_format=fmt)
     b = torch.randn([c], device=dev).to(dt)
@@ -82,4 +99,5 @@ with (torch.enable_grad() if which == 'bwd_fused' else torch.no_grad()):
     for _ in range(iters):
         fn()
 torch.cuda.synchronize()
-print('algorithmic bytes per launch:', (4 * x.numel() if which == 'bwd_fused' else x.numel() + fn().numel()) * x.element_size())
+alg = {'bwd_fused': 4 * x.numel() * x.element_size(), 'wgrad': 2 * x.numel() * 2 + 64 * 9 * 64 * 4, 'torgb': x.numel() * 2 + n * 4 * r * r * 4}.get(which)
+print('algorithmic bytes per launch:', alg if alg is not None else (x.numel() + fn().numel()) * x.element_size())
