@@ -357,7 +357,7 @@ def main():
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement (separate passes, calibrated) of this kernel on its
             # dominant shape as a ratio to the algorithmic bytes; applied here to this run's bytes per launch.
             traffic = traffic_source = None
-            for src in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+            for src in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', src)))['kernels'].get(name)
                     if pmc:

@@ -860,6 +860,8 @@ void launch_nhwc_phase(const UfParams& p, hipStream_t s)
     const bool epi = UP == 1 && DN == 1 && sizeof(T) == 2 && (g_epi_act == 1 || g_epi_act == 3);
     const bool stream_rows = UP == 1 && DN == 1 && p.out_h >= (epi ? 192 : 96);
     g.rows_per_chunk = (stream_rows && p.out_h < 192) ? 16 : 32;
+    // (swept on MI355X, bf16 batch 32: 32 / 16 rows beat 64 / 32, 128 / 64 and 16 / 8 -- profiles/r03_fir_chunk_sweep.log: the row
+    // loop waits for each next row, so longer chunks buy less halo traffic but not more bytes in flight)
     g.nchunks = (uint32_t)((p.out_h + (int)g.rows_per_chunk - 1) / (int)g.rows_per_chunk);
     g.total = (uint32_t)p.n * g.nchunks * g.gx * g.cv;
     g.cv_div = make_fastdiv(g.cv); g.gx_div = make_fastdiv(g.gx); g.chunk_div = make_fastdiv(g.nchunks);

@@ -1,5 +1,7 @@
 #!/bin/bash
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd $R
-timeout -k 10 300 python tools/bench_modconv.py > gpurun_out/r3_modconv_microbench2.log 2>&1; echo rc=$?; grep -E "fused kernel|three launches|speed-up" gpurun_out/r3_modconv_microbench2.log | cut -c1-200
-timeout -k 10 400 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "modconv or wgrad or gradfix" > gpurun_out/wg_tests.log 2>&1; echo rc=$?; tail -3 gpurun_out/wg_tests.log | cut -c1-220
+for cfg in "MG_FIR_CHUNK_BIG=32 MG_FIR_CHUNK_MID=16" "MG_FIR_CHUNK_BIG=64 MG_FIR_CHUNK_MID=32" "MG_FIR_CHUNK_BIG=128 MG_FIR_CHUNK_MID=64" "MG_FIR_CHUNK_BIG=16 MG_FIR_CHUNK_MID=8"; do
+echo "== $cfg"
+env $cfg timeout -k 10 300 python tools/microbench.py --layout nhwc --batch 32 --dtype bfloat16 2>&1 | grep -E "upfirdn2d 4x4 1:1 \[32,(64|128)" | cut -c1-100
+done
