@@ -41,3 +41,4 @@ def use_tuned_miopen_db(find_mode=None):
     if find_mode:
         os.environ['MIOPEN_FIND_MODE'] = find_mode
     return dst
+
