@@ -30,6 +30,7 @@ struct UfParams {
 };
 
 #include "mg_act.h"
+#include <type_traits>
 
 // EPI = 0: none; 1 / 3: epilogue with the linear / leaky-ReLU activation
 template <class T, int EPI, int VEC> struct UfEpiLane {
@@ -779,13 +780,17 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UfParams p, NhwcGrid 
     int in_row_off = ((int)n * p.in_h + iy) * in_pitch;
     unsigned out_row_off = (unsigned)(((int)n * p.out_h + oy_begin - (FH - 1)) * out_pitch);      // row of output j - (FH-1) at j = 0
 
-    auto load_row = [&](u32x4_t (&dst)[FW]) {
-        const bool row_ok = iy >= 0 && iy < p.in_h;
+    // one input row of the lane's FW columns.  Branch-free: a column outside the image, a row outside the image and a row past the
+    // end of the chunk (`live` false) all turn into an out-of-range offset by OR-ing the top bit in, and the load returns zeros --
+    // written as `ok ? offset : BAD` the compiler built an if / else with one load per side, and every join cost a `vmcnt(0)`
+    unsigned col_u[FW], col_bad[FW];
+    #pragma unroll
+    for (int kx = 0; kx < FW; kx++) { col_u[kx] = col_off[kx] >= 0 ? (unsigned)col_off[kx] : 0u; col_bad[kx] = col_off[kx] >= 0 ? 0u : BAD; }
+    auto load_row = [&](u32x4_t (&dst)[FW], bool live) __attribute__((always_inline)) {
+        const unsigned row_bad = (live && iy >= 0 && iy < p.in_h) ? 0u : BAD;
         #pragma unroll
-        for (int kx = 0; kx < FW; kx++) {
-            const unsigned off = (row_ok && col_off[kx] >= 0) ? (unsigned)(in_row_off + col_off[kx]) : BAD;
-            dst[kx] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
-        }
+        for (int kx = 0; kx < FW; kx++)
+            dst[kx] = __builtin_amdgcn_raw_buffer_load_b128(rin, ((unsigned)in_row_off + col_u[kx]) | row_bad | col_bad[kx], 0, 0);
         iy++; in_row_off += in_pitch;
     };
 
@@ -801,48 +806,62 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_rows(UfParams p, NhwcGrid 
         if (!EPI) return 0.f;
         return UfEpiLane<T, EPI, VEC>::noise_at(rnz, (orow >= oy_begin && orow < p.out_h) ? nz_base + (unsigned)orow * nz_pitch : UfEpiLane<T, EPI, VEC>::NZ_BAD);
     };
-    u32x4_t cur[FW], nxt[FW];
-    load_row(cur);
-    float nz_cur = load_noise(oy_begin - (FH - 1)), nz_nxt = 0.f;
-    for (int jb = 0; jb < rows_in; jb += FH) {
+    // two rows ahead: row j + 2 is requested before row j is consumed, so a lane has 8 sixteen-byte loads in flight (one row ahead: 4 --
+    // ~49 KB per CU against the ~39 KB that 5 TB/s at ~2 us of latency asks for; the loop waited for every next row).  The rows live in
+    // a ring of FH buffers indexed by the unrolled row counter: no register copies (a `cur = nxt` copy made the compiler wait for the
+    // youngest load), no branches around the requests (a row past the end is requested out of range), whole groups of FH rows without
+    // a trip test -- so the wait in front of row j can leave row j + 1 in flight (`s_waitcnt vmcnt(8..11)` in the ISA).  178 VGPRs = 2 waves per
+    // SIMD (126 = 4 before): the same 64 KB in flight per CU from half the waves, +6-10 % (122 against 130 us at [32,64,257^2 -> 256^2], 59.5
+    // against 64 us at 128^2, fused epilogue 195 against 214 us); capped at 168 VGPRs for 3 waves the ring spills and loses (134 us).
+    u32x4_t ring[FH][FW];
+    float nzr[FH];
+    load_row(ring[0], true);
+    nzr[0] = load_noise(oy_begin - (FH - 1));
+    load_row(ring[1], rows_in > 1);
+    nzr[1] = load_noise(oy_begin + 1 - (FH - 1));
+    auto step = [&](auto R, int j) __attribute__((always_inline)) {
+        constexpr int r = decltype(R)::value;
+        load_row(ring[(r + 2) % FH], j + 2 < rows_in);
+        nzr[(r + 2) % FH] = load_noise(oy_begin + j + 2 - (FH - 1));
+        f2_t row[FW][VEC / 2];
         #pragma unroll
-        for (int r = 0; r < FH; r++) {
-            const int j = jb + r;
-            if (j >= rows_in) break;
-            if (j + 1 < rows_in) { load_row(nxt); nz_nxt = load_noise(oy_begin + j + 1 - (FH - 1)); }
-            f2_t row[FW][VEC / 2];
+        for (int kx = 0; kx < FW; kx++) nhwc_unpack2<T>(ring[r][kx], row[kx]);
+        #pragma unroll
+        for (int ky = 0; ky < FH; ky++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int slot = ((r - ky) % FH + FH) % FH;                         // output row j - ky
             #pragma unroll
-            for (int kx = 0; kx < FW; kx++) nhwc_unpack2<T>(cur[kx], row[kx]);
-            #pragma unroll
-            for (int ky = 0; ky < FH; ky++) {
-                const int slot = ((r - ky) % FH + FH) % FH;                         // output row j - ky
+            for (int kx = 0; kx < FW; kx++) {
+                const f2_t tap = {ft[ky][kx], ft[ky][kx]};
                 #pragma unroll
-                for (int kx = 0; kx < FW; kx++) {
-                    const f2_t tap = {ft[ky][kx], ft[ky][kx]};
-                    #pragma unroll
-                    for (int e = 0; e < VEC / 2; e++) acc[slot][e] = __builtin_elementwise_fma(row[kx][e], tap, acc[slot][e]);
-                }
+                for (int e = 0; e < VEC / 2; e++) acc[slot][e] = __builtin_elementwise_fma(row[kx][e], tap, acc[slot][e]);
             }
-            const int done = (r + 1) % FH;                                          // output row j - (FH-1) is complete
-            if (j >= FH - 1) {
-                if (EPI) {
-                    float t[VEC];
-                    #pragma unroll
-                    for (int h = 0; h < VEC / 2; h++) { t[2 * h] = acc[done][h].x; t[2 * h + 1] = acc[done][h].y; }
-                    epi.apply(p, t, nz_cur);
-                    __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack<T>(t), rout, out_row_off + st_off, 0, 0);
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack2<T>(acc[done]), rout, out_row_off + st_off, 0, 0);
-                }
-            }
-            out_row_off += (unsigned)out_pitch;
-            #pragma unroll
-            for (int e = 0; e < VEC / 2; e++) acc[done][e] = (f2_t){0.f, 0.f};
-            #pragma unroll
-            for (int kx = 0; kx < FW; kx++) cur[kx] = nxt[kx];
-            nz_cur = nz_nxt;
         }
+        constexpr int done = (r + 1) % FH;                                      // output row j - (FH-1) is complete
+        // (rows in front of the chunk are "stored" out of range: no branch)
+        const unsigned st_bad = j >= FH - 1 ? 0u : BAD;
+        if (EPI) {
+            float t[VEC];
+            #pragma unroll
+            for (int h = 0; h < VEC / 2; h++) { t[2 * h] = acc[done][h].x; t[2 * h + 1] = acc[done][h].y; }
+            epi.apply(p, t, nzr[r]);
+            __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack<T>(t), rout, (out_row_off + st_off) | st_bad, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(nhwc_pack2<T>(acc[done]), rout, (out_row_off + st_off) | st_bad, 0, 0);
+        }
+        out_row_off += (unsigned)out_pitch;
+        #pragma unroll
+        for (int e = 0; e < VEC / 2; e++) acc[done][e] = (f2_t){0.f, 0.f};
+    };
+    int j = 0;
+    for (; j + FH <= rows_in; j += FH) {
+        step(std::integral_constant<int, 0>(), j); step(std::integral_constant<int, 1>(), j + 1);
+        step(std::integral_constant<int, 2>(), j + 2); step(std::integral_constant<int, 3>(), j + 3);
     }
+    static_assert(FH == 4, "the row ring is written out for 4 taps");
+    if (j < rows_in) step(std::integral_constant<int, 0>(), j);
+    if (j + 1 < rows_in) step(std::integral_constant<int, 1>(), j + 1);
+    if (j + 2 < rows_in) step(std::integral_constant<int, 2>(), j + 2);
 }
 
 static thread_local int g_epi_act = 0;          // set by mg_upfirdn2d_epilogue around its launch (0: plain upfirdn2d)

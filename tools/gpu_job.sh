@@ -1,11 +1,6 @@
 #!/bin/bash
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd $R
-for v in hipblaslt rocblas hipblaslt; do
-MG_BLAS=$v timeout -k 10 500 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --prof-steps 0 > gpurun_out/r3_bench_b32_blas_$v.json 2> gpurun_out/r3_bench_b32_blas_$v.err || exit 1
-python - <<P
-import json
-d = json.loads(open('gpurun_out/r3_bench_b32_blas_$v.json').read().strip().splitlines()[-1])
-print('MG_BLAS=$v', d['ms_per_step'], d['host_enqueue_ms_per_step'], d['value'], d['config']['blas'][:30])
-P
-done
+timeout -k 10 300 python tools/microbench.py --layout nhwc --batch 32 --dtype bfloat16 2>&1 | grep -E "upfirdn2d 4x4 1:1 \[32,(64|128)" | cut -c1-100
+timeout -k 10 200 python tools/bench_blur_epilogue.py 2>&1 | grep -E "\[32,64" | cut -c1-120
+timeout -k 10 400 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "upfirdn or blur or nhwc" 2>&1 | tail -3 | cut -c1-200

@@ -39,3 +39,7 @@ for e in sorted(prof.key_averages(), key=lambda e: -e.count)[:60]:
 print('---- by self cpu time')
 for e in sorted(prof.key_averages(), key=lambda e: -e.self_cpu_time_total)[:40]:
     print(f'{e.count:6d}  {e.key:48s} self cpu {e.self_cpu_time_total / 1e3:8.1f} ms')
+
+print('---- GEMM-like ops by input shapes')
+for e in sorted([e for e in prof.key_averages(group_by_input_shape=True) if e.key in ('aten::mm', 'aten::addmm', 'aten::bmm', 'aten::baddbmm', 'aten::einsum', 'aten::matmul', 'aten::linear')], key=lambda e: -e.count)[:40]:
+    print(f'{e.count:6d}  {e.key:16s} {str(e.input_shapes)[:110]:110s} self cpu {e.self_cpu_time_total / 1e3:7.2f} ms')
