@@ -632,6 +632,9 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
         const int ix = ix0 + rx;
         col_off[rx] = (ix >= 0 && ix < p.in_w) ? ix * pix_bytes + (int)cvi * 16 : -1;
     }
+    unsigned col_u[RX], col_bad[RX];
+    #pragma unroll
+    for (int rx = 0; rx < RX; rx++) { col_u[rx] = col_off[rx] >= 0 ? (unsigned)col_off[rx] : 0u; col_bad[rx] = col_off[rx] >= 0 ? 0u : BAD; }
     unsigned st_off[MX];
     #pragma unroll
     for (int i = 0; i < MX; i++) st_off[i] = (ox0 + i < p.out_w) ? (unsigned)((ox0 + i) * pix_bytes + (int)cvi * 16) : BAD;
@@ -670,13 +673,13 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc(UfParams p, NhwcGrid g)
                 const int ry = ry0 + r;
                 if (ry >= RY) break;
                 const int iy = iy0 + ry;
-                const bool row_ok = iy >= 0 && iy < p.in_h;
-                const int row_off = ((int)n * p.in_h + iy) * in_pitch;
+                // (branch-free: an absent row / column ORs the top bit into the offset and the load returns zeros; as a select the
+                // compiler built an if / else with one load per side)
+                const unsigned row_bad = (iy >= 0 && iy < p.in_h) ? 0u : BAD;
+                const unsigned row_off = (unsigned)(((int)n * p.in_h + iy) * in_pitch);
                 #pragma unroll
-                for (int rx = 0; rx < RX; rx++) {
-                    const unsigned off = (row_ok && col_off[rx] >= 0) ? (unsigned)(row_off + col_off[rx]) : BAD;
-                    raw[r][rx] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
-                }
+                for (int rx = 0; rx < RX; rx++)
+                    raw[r][rx] = __builtin_amdgcn_raw_buffer_load_b128(rin, (row_off + col_u[rx]) | row_bad | col_bad[rx], 0, 0);
             }
             #pragma unroll
             for (int r = 0; r < RG; r++) {
