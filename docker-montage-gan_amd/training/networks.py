@@ -31,6 +31,7 @@ from ..torch_utils.ops import mbstd
 from ..torch_utils.ops import torgb
 from ..torch_utils.ops import modconv_epilogue
 from ..torch_utils.ops import modconv3x3
+from ..torch_utils.ops import fromrgb
 from ..torch_utils.ops import upfirdn2d
 from . import weight_prep
 
@@ -198,6 +199,10 @@ class Conv2dLayer(torch.nn.Module):
     def forward(self, x, gain=1):
         w = weight_prep.get(self.weight, self.weight_gain, x.dtype)           # (weight * weight_gain).to(x.dtype)
         b = weight_prep.get(self.bias, 1, x.dtype) if self.bias is not None else None        # bias.to(x.dtype)
+        if (self.up == 1 and self.down == 1 and self.padding == 0 and self.activation in ('linear', 'lrelu') and fromrgb.applicable(x, w)):
+            # the discriminator's FromRGB (<= 4 -> 64..512 channels, 1x1): convolution + bias_act in ONE pass over the wide tensor
+            return fromrgb.fromrgb(x, w, b, act=self.activation, gain=self.act_gain * gain,
+                                   clamp=self.conv_clamp * gain if self.conv_clamp is not None else None)
         if (self.activation in ('linear', 'lrelu') and modconv3x3.applicable(x, w, up=self.up, down=self.down)
                 and w.is_contiguous(memory_format=torch.channels_last)):
             # 64 -> 64 channels at full resolution (the discriminator's first conv0): convolution + bias_act in ONE kernel

@@ -78,7 +78,8 @@ enum {
     MG_K_MBSTD = 22,
     MG_K_TORGB = 23,
     MG_K_WGRAD = 24,
-    MG_K_COUNT = 25
+    MG_K_FROMRGB = 25,
+    MG_K_COUNT = 26
 };
 
 int         mg_abi_version(void);
@@ -265,6 +266,18 @@ int mg_modconv3x3_c64(const void* x, const void* w, const float* s, const float*
  */
 int mg_wgrad3x3_c64(const void* dy, const void* x, const float* s, const void* w, float* dw, float* ds,
                     int32_t n, int32_t h, int32_t wd, void* stream);
+/*
+ * mg_fromrgb_nhwc_{fwd,bwd}: the discriminator's FromRGB layer in one pass each way (reference training/networks.py:589-594
+ * `y = self.fromrgb(img)`: Conv2dLayer :138-186 = conv2d_resample 1x1, I = img_channels <= 4 -> C in {64,128,256,512}, then
+ * bias_act(lrelu | linear, gain, clamp)).  x [pixels, I], y / dy [pixels, C] channels-last T = bf16 | fp16; w [C, I] T; b [C] T or NULL.
+ * fwd: y = T(bias_act(T(conv), b)).  bwd: dpre = T(dy * act'(y) * gain where |y| < clamp) is never stored; dx [pixels, I] (or NULL) =
+ * T(sum_c w[c][i] dpre[c]); gw32 [C, I] and gb32 [C] (or NULL) are float32 accumulators ZERO-FILLED by the caller; gw / gb receive them
+ * cast to T by a second tiny launch (what aten's convolution_backward / bias_act's bias gradient return).  act = 1 | 3.
+ */
+int mg_fromrgb_nhwc_fwd(const void* x, const void* w, const void* b, void* y, int dtype, int act, float alpha, float gain, float clamp,
+                        int64_t pixels, int32_t c, int32_t i, void* stream);
+int mg_fromrgb_nhwc_bwd(const void* x, const void* w, const void* y, const void* dy, void* dx, float* gw32, float* gb32, void* gw, void* gb,
+                        int dtype, int act, float alpha, float gain, float clamp, int64_t pixels, int32_t c, int32_t i, void* stream);
 /* diagnostics: while `buf` (device memory, uint64[8]) is set, workgroup 0 of mg_modconv3x3_c64 leaves its cycle counts per phase
  * (stage, prefetch issue, MFMA loop, epilogue, store) there; NULL switches it off (tools/bench_modconv.py). */
 void mg_modconv_debug_timing(void* buf);

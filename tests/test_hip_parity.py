@@ -747,6 +747,77 @@ def test_torgb_one_pass_matches_the_four_launches(native, dtype):
         close_lowp(u.float().cpu().numpy(), v.float().cpu().numpy(), dtype, f'second order grad {nm}', tol=4 * LOWP_TOL[dtype])
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_fromrgb_one_pass_matches_the_two_launches(native, dtype):
+    """ops/fromrgb.py: the discriminator's FromRGB (1x1 convolution from <= 4 channels + bias_act) as one native pass each way against
+    the two launches it replaces: values, the three first-order gradients (with and without a gradient for the image), and the R1 shape
+    of a second differentiation (create_graph=True runs the composition's own backward inside the same Function).  Integer-valued
+    data with a gain of 1 makes every product and sum exact on both sides, so those cases must agree BIT FOR BIT; random data within
+    the tolerance of the 16-bit type.  Ragged pixel counts, 3 and 4 image channels, a clamp that bites, lrelu and linear."""
+    FR = op('fromrgb')
+    g = torch.Generator(device=DEV).manual_seed(6)
+    for (n, i, c, h, w, act, clamp) in [(2, 4, 64, 24, 40, 'lrelu', 6.0), (3, 3, 128, 9, 7, 'lrelu', None), (2, 4, 256, 16, 16, 'linear', 2.5),
+                                        (1, 4, 512, 8, 8, 'lrelu', 4.0), (5, 4, 64, 33, 31, 'lrelu', 3.0), (2, 1, 64, 5, 5, 'lrelu', None)]:
+        for exact in (True, False):
+            if exact:       # small integers and alpha = 0.5, gain = 1: every intermediate representable in both 16-bit types
+                x = torch.randint(-3, 4, [n, i, h, w], device=DEV, generator=g).to(dtype)
+                wt = torch.randint(-3, 4, [c, i, 1, 1], device=DEV, generator=g).to(dtype)
+                b = torch.randint(-3, 4, [c], device=DEV, generator=g).to(dtype)
+                gy = torch.randint(-4, 5, [n, c, h, w], device=DEV, generator=g).to(dtype)
+                kw = dict(act=act, alpha=0.5, gain=1.0, clamp=clamp)
+            else:
+                x = torch.randn([n, i, h, w], device=DEV, generator=g).to(dtype)
+                wt = (torch.randn([c, i, 1, 1], device=DEV, generator=g) / i ** 0.5).to(dtype)
+                b = torch.randn([c], device=DEV, generator=g).to(dtype)
+                gy = torch.randn([n, c, h, w], device=DEV, generator=g).to(dtype)
+                kw = dict(act=act, clamp=clamp)
+            gy = gy.contiguous(memory_format=torch.channels_last)
+            for image_grad in (True, False):
+                xx = x.contiguous(memory_format=torch.channels_last).requires_grad_(image_grad)
+                ww, bb = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+                leaves = ([xx] if image_grad else []) + [ww, bb]
+                before = native.launch_count(native.K_FROMRGB)
+                y = FR.fromrgb(xx, ww, bb, **kw)
+                g1 = torch.autograd.grad([y], leaves, [gy])
+                assert native.launch_count(native.K_FROMRGB) == before + 2, 'the native forward and backward passes did not run'
+                assert y.is_contiguous(memory_format=torch.channels_last) and y.dtype == dtype
+                FR.enabled = False
+                try:
+                    y2 = FR.fromrgb(xx, ww, bb, **kw)
+                    g2 = torch.autograd.grad([y2], leaves, [gy])
+                finally:
+                    FR.enabled = True
+                assert native.launch_count(native.K_FROMRGB) == before + 2
+                what = f'{(n, i, c, h, w, act, clamp)} exact={exact} image_grad={image_grad}'
+                names = (['x'] if image_grad else []) + ['w', 'b']
+                if exact:
+                    assert torch.equal(y, y2), what
+                    for u, v, nm in zip(g1, g2, names):
+                        assert torch.equal(u.float(), v.float()), f'{what}: grad {nm}'
+                else:
+                    close_lowp(y.detach().float().cpu().numpy(), y2.detach().float().cpu().numpy(), dtype, what + ' fwd')
+                    for u, v, nm in zip(g1, g2, names):
+                        # dW / db: sums of n*h*w terms, rounded to the 16-bit type once here and once by the library / the reduction
+                        close_lowp(u.float().cpu().numpy(), v.float().cpu().numpy(), dtype, f'{what}: grad {nm}', tol=4 * LOWP_TOL[dtype])
+    # second order, the R1 shape: d/dw, d/db of |d sum(y) / dx|^2 through both forms
+    n, i, c, h, w = 2, 4, 64, 8, 8
+    x = torch.randn([n, i, h, w], device=DEV, generator=g).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wt = (torch.randn([c, i, 1, 1], device=DEV, generator=g) / 2).to(dtype).requires_grad_(True)
+    b = (torch.randn([c], device=DEV, generator=g) / 4).to(dtype).requires_grad_(True)
+    mix = torch.randn([n, c, h, w], device=DEV, generator=g).to(dtype)
+    outs = []
+    for flag in (True, False):
+        FR.enabled = flag
+        try:
+            y = FR.fromrgb(x, wt, b, act='lrelu', clamp=256)
+            gx, = torch.autograd.grad([(y.float() * mix.float()).sum()], [x], create_graph=True)
+            outs.append(torch.autograd.grad([gx.float().square().sum()], [wt]))
+        finally:
+            FR.enabled = True
+    for u, v, nm in zip(outs[0], outs[1], ['w']):
+        close_lowp(u.float().cpu().numpy(), v.float().cpu().numpy(), dtype, f'second order grad {nm}', tol=4 * LOWP_TOL[dtype])
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
 def test_filtered_lrelu_matches_composition(native, dtype):
     FL, U = op('filtered_lrelu'), op('upfirdn2d')
