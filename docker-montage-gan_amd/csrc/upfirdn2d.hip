@@ -80,8 +80,39 @@ template <class T, int EPI, int VEC> struct UfEpiLane {
     __device__ __forceinline__ void apply(const UfParams& p, float (&v)[VEC], float nz) const
     {
         if (EPI == 0) return;
-        const BaConst<float> k = {p.ep_alpha, p.ep_gain, p.ep_clamp};
         const bool has_nz = p.ep_noise != nullptr;
+        if constexpr (std::is_same<T, mg_bf16>::value) {
+            // bfloat16: two values per instruction (v_pk_mul / v_pk_fma / v_pk_add_f32, v_cvt_pk_bf16_f32) -- the epilogue doubled the
+            // VALU count of the row kernel, which made the fused pass VALU-bound (214 us against 136 us for the filter alone).  The same
+            // operations in the same order as ba_eval: T(fir) * d, + noise * strength, -> T, + b, lrelu as max(t, alpha t) (0 <= alpha <= 1,
+            // checked by the entry point), * gain, clamp as v_med3 (a NaN comes out as -clamp, as the comparison chain leaves it).
+            typedef float e2_t __attribute__((ext_vector_type(2)));
+            typedef __bf16 ebf2_t __attribute__((ext_vector_type(2)));
+            auto round2 = [](e2_t x) -> e2_t {
+                const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, ebf2_t));
+                e2_t r; r.x = __builtin_bit_cast(float, u << 16); r.y = __builtin_bit_cast(float, u & 0xFFFF0000u); return r;
+            };
+            const e2_t nz2 = {nz, nz}, st2 = {st, st}, g2 = {p.ep_gain, p.ep_gain}, a2 = {p.ep_alpha, p.ep_alpha};
+            const float lim = p.ep_clamp;
+            #pragma unroll
+            for (int h = 0; h < VEC / 2; h++) {
+                e2_t t = {v[2 * h], v[2 * h + 1]};
+                const e2_t d2 = {d[2 * h], d[2 * h + 1]}, b2 = {b[2 * h], b[2 * h + 1]};
+                t = round2(t) * d2;                                         // the filter's output is a T tensor
+                const e2_t tn = __builtin_elementwise_fma(nz2, st2, t);
+                t = has_nz ? tn : t;                                        // (a select: without noise the value must stay untouched, -0 included)
+                t = round2(t) + b2;
+                if (EPI == 3) {
+                    const e2_t m = t * a2;
+                    t.x = __builtin_fmaxf(t.x, m.x); t.y = __builtin_fmaxf(t.y, m.y);
+                }
+                t = t * g2;
+                if (lim >= 0.f) { t.x = __builtin_amdgcn_fmed3f(t.x, -lim, lim); t.y = __builtin_amdgcn_fmed3f(t.y, -lim, lim); }
+                v[2 * h] = t.x; v[2 * h + 1] = t.y;
+            }
+            return;
+        }
+        const BaConst<float> k = {p.ep_alpha, p.ep_gain, p.ep_clamp};
         #pragma unroll
         for (int e = 0; e < VEC; e++) {
             float t = (float)to_acc<T>(from_acc<T>(v[e])) * d[e];           // the filter's output is a T tensor
@@ -878,9 +909,7 @@ void launch_nhwc_phase(const UfParams& p, hipStream_t s)
     g.gx = (uint32_t)((p.out_w + MX - 1) / MX);
     // rows per chunk: a multiple of MY; 32 output rows keep the inter-chunk halo small while leaving >= 8 workgroups per CU on the big layers
     // (row streaming from 96 rows up: 16-row chunks at 128^2 re-read 3 rows in 16 where the block kernel re-reads 3 in 4)
-    // (with the epilogue on the way out the block kernel stays ahead below 192 rows: 91 against 103 us at [32,128,128,128])
-    const bool epi = UP == 1 && DN == 1 && sizeof(T) == 2 && (g_epi_act == 1 || g_epi_act == 3);
-    const bool stream_rows = UP == 1 && DN == 1 && p.out_h >= (epi ? 192 : 96);
+    const bool stream_rows = UP == 1 && DN == 1 && p.out_h >= 96;
     g.rows_per_chunk = (stream_rows && p.out_h < 192) ? 16 : 32;
     // (swept on MI355X, bf16 batch 32: 32 / 16 rows beat 64 / 32, 128 / 64 and 16 / 8 -- profiles/r03_fir_chunk_sweep.log: the row
     // loop waits for each next row, so longer chunks buy less halo traffic but not more bytes in flight)
@@ -1032,6 +1061,7 @@ extern "C" int mg_upfirdn2d_epilogue(const void* x, const float* f, void* y, int
     MG_REQUIRE(x && f && y, "x must reside on the device");
     MG_REQUIRE(dtype == MG_F16 || dtype == MG_BF16, "upfirdn2d_epilogue: float16 / bfloat16 channels-last tensors only");
     MG_REQUIRE(act == 1 || act == 3, "upfirdn2d_epilogue: activation must be linear (1) or lrelu (3)");
+    MG_REQUIRE(act != 3 || (alpha >= 0.f && alpha <= 1.f), "upfirdn2d_epilogue: leaky-ReLU slope must lie in [0, 1]");
     MG_REQUIRE(f_size[0] >= 1 && f_size[1] >= 1 && f_size[0] <= 4 && f_size[1] <= 4, "upfirdn2d_epilogue: filters of at most 4x4 taps");
     MG_REQUIRE(x_size[0] == y_size[0] && x_size[1] == y_size[1] && y_size[2] >= 1 && y_size[3] >= 1, "x and y must agree in batch and channels");
     const int64_t C = x_size[1];
