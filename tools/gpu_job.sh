@@ -1,5 +1,11 @@
 #!/bin/bash
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd $R
-timeout -k 10 400 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "blur or epilogue or upfirdn" 2>&1 | tail -4 | cut -c1-250
-timeout -k 10 200 python tools/bench_blur_epilogue.py 2>&1 | grep -E "fused=True|blur alone" | cut -c1-120
+timeout -k 10 200 python tools/bench_blur_epilogue.py > gpurun_out/r03_blur_epilogue_microbench.log 2>&1; echo rc=$?
+timeout -k 10 600 python bench.py > gpurun_out/r03_bench_b32_final.json 2> gpurun_out/r03_bench_b32_final.err || exit 1
+python - <<P
+import json
+d = json.loads(open('gpurun_out/r03_bench_b32_final.json').read().strip().splitlines()[-1])
+print('default', d['ms_per_step'], d['host_enqueue_ms_per_step'], d['value'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline']['all_kernels']['upfirdn2d_nhwc'])
+P
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/r3_gpu_tests.log 2>&1; echo rc=$?; tail -3 gpurun_out/r3_gpu_tests.log | cut -c1-220
