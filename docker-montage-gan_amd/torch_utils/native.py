@@ -29,11 +29,12 @@ K_MBSTD = 22
 K_TORGB = 23
 K_WGRAD = 24
 K_FROMRGB = 25
+K_RESIDUAL = 26
 GS_SLOTS = 64       # MG_GS_SLOTS
 KERNEL_NAMES = {0: 'upfirdn2d_generic', 1: 'upfirdn2d_tiled', 2: 'bias_act', 3: 'fma_bias_act', 4: 'alpha_composite_fwd',
                 5: 'alpha_composite_bwd', 6: 'translate_fwd', 7: 'translate_bwd_input', 8: 'translate_bwd_shift',
                 9: 'filtered_lrelu', 10: 'bwd_fused', 11: 'upfirdn2d_stream', 12: 'upfirdn2d_nhwc',
-                13: 'affine_warp_fwd', 14: 'affine_warp_bwd', 15: 'channel_mix', 16: 'demod', 18: 'stats', 19: 'ada_params', 20: 'modconv', 21: 'upfirdn2d_sep', 22: 'mbstd', 23: 'torgb', 24: 'wgrad', 25: 'fromrgb'}
+                13: 'affine_warp_fwd', 14: 'affine_warp_bwd', 15: 'channel_mix', 16: 'demod', 18: 'stats', 19: 'ada_params', 20: 'modconv', 21: 'upfirdn2d_sep', 22: 'mbstd', 23: 'torgb', 24: 'wgrad', 25: 'fromrgb', 26: 'residual'}
 
 _lib = None
 _lock = threading.RLock()
@@ -129,6 +130,8 @@ def _declare(L):
     L.mg_demod_bwd.argtypes = [c_void_p] * 7 + [c_i32] * 5 + [c_void_p]
     L.mg_modconv3x3_c64.argtypes = [c_void_p] * 10 + [c_i32, c_i32, c_i32, c_i64, c_int, c_float, c_float, c_float, c_void_p]
     L.mg_wgrad3x3_c64.argtypes = [c_void_p] * 6 + [c_i32, c_i32, c_i32, c_void_p]
+    L.mg_residual_bias_act_fwd.argtypes = [c_void_p] * 4 + [c_int, c_int, c_float, c_float, c_float, c_float, c_i64, c_i32, c_void_p]
+    L.mg_residual_bias_act_bwd.argtypes = [c_void_p] * 6 + [c_int, c_int, c_float, c_float, c_float, c_float, c_i64, c_i32, c_void_p]
     L.mg_fromrgb_nhwc_fwd.argtypes = [c_void_p] * 4 + [c_int, c_int, c_float, c_float, c_float, c_i64, c_i32, c_i32, c_void_p]
     L.mg_fromrgb_nhwc_bwd.argtypes = [c_void_p] * 9 + [c_int, c_int, c_float, c_float, c_float, c_i64, c_i32, c_i32, c_void_p]
     L.mg_torgb_nhwc_fwd.argtypes = [c_void_p] * 5 + [c_int, c_i32, c_i32, c_i32, c_i32, c_float, c_void_p]
@@ -159,7 +162,7 @@ def _declare(L):
     for name in ('mg_upfirdn2d', 'mg_upfirdn2d_index_table', 'mg_bias_act', 'mg_fma_bias_act',
                  'mg_alpha_composite_fwd', 'mg_alpha_composite_bwd', 'mg_translate_sample_fwd',
                  'mg_translate_sample_bwd_input', 'mg_translate_sample_bwd_shift', 'mg_filtered_lrelu', 'mg_bwd_fused',
-                 'mg_fma_bias_act_nhwc', 'mg_bwd_fused_nhwc', 'mg_affine_warp_fwd', 'mg_affine_warp_bwd', 'mg_channel_mix', 'mg_demod_fwd', 'mg_demod_bwd', 'mg_stats_accumulate', 'mg_ada_params', 'mg_modconv3x3_c64', 'mg_upfirdn2d_sep12', 'mg_reflect_pad_upsample12', 'mg_mbstd_fwd', 'mg_mbstd_bwd', 'mg_torgb_nhwc_fwd', 'mg_torgb_nhwc_bwd', 'mg_torgb_bwd_finish', 'mg_bwd_fused_nhwc_y', 'mg_upfirdn2d_epilogue', 'mg_wgrad3x3_c64', 'mg_fromrgb_nhwc_fwd', 'mg_fromrgb_nhwc_bwd',
+                 'mg_fma_bias_act_nhwc', 'mg_bwd_fused_nhwc', 'mg_affine_warp_fwd', 'mg_affine_warp_bwd', 'mg_channel_mix', 'mg_demod_fwd', 'mg_demod_bwd', 'mg_stats_accumulate', 'mg_ada_params', 'mg_modconv3x3_c64', 'mg_upfirdn2d_sep12', 'mg_reflect_pad_upsample12', 'mg_mbstd_fwd', 'mg_mbstd_bwd', 'mg_torgb_nhwc_fwd', 'mg_torgb_nhwc_bwd', 'mg_torgb_bwd_finish', 'mg_bwd_fused_nhwc_y', 'mg_upfirdn2d_epilogue', 'mg_wgrad3x3_c64', 'mg_fromrgb_nhwc_fwd', 'mg_fromrgb_nhwc_bwd', 'mg_residual_bias_act_fwd', 'mg_residual_bias_act_bwd',
                  'mg_prof_enable', 'mg_prof_collect', 'mg_prof_reset'):
         getattr(L, name).restype = c_int
 

@@ -32,6 +32,7 @@ from ..torch_utils.ops import torgb
 from ..torch_utils.ops import modconv_epilogue
 from ..torch_utils.ops import modconv3x3
 from ..torch_utils.ops import fromrgb
+from ..torch_utils.ops import residual_bias_act
 from ..torch_utils.ops import upfirdn2d
 from . import weight_prep
 
@@ -173,6 +174,7 @@ class Conv2dLayer(torch.nn.Module):
         self.activation = activation
         self.up, self.down = up, down
         self.conv_clamp = conv_clamp
+        self.out_channels_ = out_channels
         self.register_buffer('resample_filter', upfirdn2d.setup_filter(_default(resample_filter, [1, 3, 3, 1])))
         self.padding = kernel_size // 2
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
@@ -195,6 +197,15 @@ class Conv2dLayer(torch.nn.Module):
         if self.bias is not None and dtype != torch.float32 and isinstance(self.bias, torch.nn.Parameter):
             ents.append((self.bias, 1, dtype))
         return ents
+
+    def conv_only(self, x):
+        """The layer without its bias_act: (raw convolution output, bias in x.dtype or None) -- for callers that fuse the element-wise
+        tail with what follows (DiscriminatorBlock's residual add)."""
+        w = weight_prep.get(self.weight, self.weight_gain, x.dtype)
+        b = weight_prep.get(self.bias, 1, x.dtype) if self.bias is not None else None
+        y = conv2d_resample.conv2d_resample(x=x, w=w, f=self.resample_filter, up=self.up, down=self.down,
+                                            padding=self.padding, flip_weight=(self.up == 1))
+        return y, b
 
     def forward(self, x, gain=1):
         w = weight_prep.get(self.weight, self.weight_gain, x.dtype)           # (weight * weight_gain).to(x.dtype)
@@ -648,10 +659,22 @@ class DiscriminatorBlock(torch.nn.Module):
             x = x + y if x is not None else y
             img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
         if self.architecture == 'resnet':
-            y = self.skip(x, gain=np.sqrt(0.5))
-            x = self.conv0(x)
-            x = self.conv1(x, gain=np.sqrt(0.5))
-            x = y.add_(x)
+            g = np.sqrt(0.5)
+            if (residual_bias_act.enabled and x.is_cuda and x.dtype != torch.float32 and fmt == torch.channels_last
+                    and self.skip.bias is None and self.skip.activation == 'linear' and self.skip.conv_clamp is None
+                    and self.conv1.activation in ('linear', 'lrelu') and self.conv1.out_channels_ in (64, 128, 256, 512)):
+                # the two bias_act calls and the add as one pass over the block's output (ops/residual_bias_act.py); same values
+                y_raw, _ = self.skip.conv_only(x)
+                x = self.conv0(x)
+                x_raw, b1 = self.conv1.conv_only(x)
+                x = residual_bias_act.residual_bias_act(
+                    x_raw, b1, y_raw, act=self.conv1.activation, gain=self.conv1.act_gain * g,
+                    clamp=self.conv1.conv_clamp * g if self.conv1.conv_clamp is not None else None, r_gain=self.skip.act_gain * g)
+            else:
+                y = self.skip(x, gain=g)
+                x = self.conv0(x)
+                x = self.conv1(x, gain=g)
+                x = y.add_(x)
         else:
             x = self.conv0(x)
             x = self.conv1(x)

@@ -79,7 +79,8 @@ enum {
     MG_K_TORGB = 23,
     MG_K_WGRAD = 24,
     MG_K_FROMRGB = 25,
-    MG_K_COUNT = 26
+    MG_K_RESIDUAL = 26,
+    MG_K_COUNT = 27
 };
 
 int         mg_abi_version(void);
@@ -278,6 +279,18 @@ int mg_fromrgb_nhwc_fwd(const void* x, const void* w, const void* b, void* y, in
                         int64_t pixels, int32_t c, int32_t i, void* stream);
 int mg_fromrgb_nhwc_bwd(const void* x, const void* w, const void* y, const void* dy, void* dx, float* gw32, float* gb32, void* gw, void* gb,
                         int dtype, int act, float alpha, float gain, float clamp, int64_t pixels, int32_t c, int32_t i, void* stream);
+/*
+ * mg_residual_bias_act_{fwd,bwd}: the tail of the discriminator's residual block (reference training/networks.py:596-600:
+ * `y = self.skip(x, gain)`, `x = self.conv1(x, gain)`, `x = y.add_(x)` -- i.e. bias_act(y_raw, None, linear, r_gain), bias_act(x_raw, b, act, gain,
+ * clamp) and the add, after the two convolutions) in one pass each way.  x, r, out, dout, dx, dr [pixels, C] channels-last T = bf16 | fp16,
+ * C in {64,128,256,512}; b [C] T or NULL.  fwd: out = T(T(bias_act(x, b)) + T(r * r_gain)).  bwd: the activation's output is recomputed from x and b;
+ * dx = T(dout * act'(.) * gain where unclamped), dr = T(dout * r_gain) (NULL: not wanted), gb32 [C] float32 ZERO-FILLED by the caller += dx
+ * (NULL: not wanted).  act = 1 | 3.
+ */
+int mg_residual_bias_act_fwd(const void* x, const void* b, const void* r, void* out, int dtype, int act, float alpha, float gain, float clamp,
+                             float r_gain, int64_t pixels, int32_t c, void* stream);
+int mg_residual_bias_act_bwd(const void* dout, const void* x, const void* b, void* dx, void* dr, float* gb32, int dtype, int act, float alpha,
+                             float gain, float clamp, float r_gain, int64_t pixels, int32_t c, void* stream);
 /* diagnostics: while `buf` (device memory, uint64[8]) is set, workgroup 0 of mg_modconv3x3_c64 leaves its cycle counts per phase
  * (stage, prefetch issue, MFMA loop, epilogue, store) there; NULL switches it off (tools/bench_modconv.py). */
 void mg_modconv_debug_timing(void* buf);

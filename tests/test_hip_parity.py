@@ -818,6 +818,75 @@ def test_fromrgb_one_pass_matches_the_two_launches(native, dtype):
         close_lowp(u.float().cpu().numpy(), v.float().cpu().numpy(), dtype, f'second order grad {nm}', tol=4 * LOWP_TOL[dtype])
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_residual_tail_one_pass_matches_the_three_launches(native, dtype):
+    """ops/residual_bias_act.py: bias_act(y_raw, linear, gain) + bias_act(x_raw, b, lrelu, gain, clamp) + add -- the tail of the
+    discriminator's residual block -- as one native pass each way against the three launches.  The arithmetic is element-wise with the
+    same rounding points, so values and dx / dy must agree BIT FOR BIT on any data; the bias gradient is a float32 sum in another order
+    (exact on integer data).  Ragged pixel counts, a clamp that bites, no bias, the linear activation, and the R1 shape of a second
+    differentiation."""
+    RS = op('residual_bias_act')
+    g = torch.Generator(device=DEV).manual_seed(9)
+    cl = torch.channels_last
+    for (n, c, h, w, act, clamp, has_b) in [(2, 64, 24, 40, 'lrelu', 1.5, True), (3, 128, 9, 7, 'lrelu', None, True), (2, 256, 5, 5, 'linear', 0.75, True),
+                                            (1, 512, 3, 3, 'lrelu', 2.0, False), (5, 64, 33, 31, 'lrelu', 181.02, True)]:
+        for exact in (True, False):
+            if exact:
+                x = torch.randint(-6, 7, [n, c, h, w], device=DEV, generator=g).to(dtype)
+                y = torch.randint(-6, 7, [n, c, h, w], device=DEV, generator=g).to(dtype)
+                b = torch.randint(-3, 4, [c], device=DEV, generator=g).to(dtype) if has_b else None
+                gy = torch.randint(-4, 5, [n, c, h, w], device=DEV, generator=g).to(dtype)
+                kw = dict(act=act, alpha=0.5, gain=2.0, clamp=clamp, r_gain=0.5)
+            else:
+                x = torch.randn([n, c, h, w], device=DEV, generator=g).to(dtype)
+                y = torch.randn([n, c, h, w], device=DEV, generator=g).to(dtype)
+                b = torch.randn([c], device=DEV, generator=g).to(dtype) if has_b else None
+                gy = torch.randn([n, c, h, w], device=DEV, generator=g).to(dtype)
+                kw = dict(act=act, gain=float(np.sqrt(2) * np.sqrt(0.5)), clamp=clamp, r_gain=float(np.sqrt(0.5)))
+            x = x.contiguous(memory_format=cl).requires_grad_(True)
+            y = y.contiguous(memory_format=cl).requires_grad_(True)
+            gy = gy.contiguous(memory_format=cl)
+            leaves = [x, y] + ([b.requires_grad_(True)] if has_b else [])
+            before = native.launch_count(native.K_RESIDUAL)
+            out = RS.residual_bias_act(x, b, y, **kw)
+            g1 = torch.autograd.grad([out], leaves, [gy])
+            assert native.launch_count(native.K_RESIDUAL) == before + 2, 'the native forward and backward passes did not run'
+            assert out.is_contiguous(memory_format=cl) and g1[0].is_contiguous(memory_format=cl)
+            RS.enabled = False
+            try:
+                out2 = RS.residual_bias_act(x, b, y, **kw)
+                g2 = torch.autograd.grad([out2], leaves, [gy])
+            finally:
+                RS.enabled = True
+            assert native.launch_count(native.K_RESIDUAL) == before + 2
+            what = f'{(n, c, h, w, act, clamp, has_b)} exact={exact}'
+            assert torch.equal(out, out2), what
+            assert torch.equal(g1[0], g2[0]), what + ': grad x'
+            assert torch.equal(g1[1], g2[1]), what + ': grad y'
+            if has_b:
+                if exact:
+                    assert torch.equal(g1[2].float(), g2[2].float()), what + ': grad b'
+                else:
+                    close_lowp(g1[2].float().cpu().numpy(), g2[2].float().cpu().numpy(), dtype, what + ': grad b', tol=4 * LOWP_TOL[dtype])
+    # second order, the R1 shape: d/db of |d sum(out * mix) / dx|^2 through both forms (the activation's slope is piecewise constant, so the
+    # interesting part is that the graph is connected and the values agree)
+    n, c, h, w = 2, 64, 8, 8
+    x = torch.randn([n, c, h, w], device=DEV, generator=g).to(dtype).contiguous(memory_format=cl).requires_grad_(True)
+    y = torch.randn([n, c, h, w], device=DEV, generator=g).to(dtype).contiguous(memory_format=cl).requires_grad_(True)
+    b = (torch.randn([c], device=DEV, generator=g) / 4).to(dtype).requires_grad_(True)
+    mix = torch.randn([n, c, h, w], device=DEV, generator=g).to(dtype).contiguous(memory_format=cl)
+    outs = []
+    for flag in (True, False):
+        RS.enabled = flag
+        try:
+            out = RS.residual_bias_act(x * 1.0, b, y * 1.0, act='lrelu', clamp=256, r_gain=0.7)
+            gx, gy2 = torch.autograd.grad([(out.float() * mix.float()).sum()], [x, y], create_graph=True)
+            outs.append((gx.detach().clone(), gy2.detach().clone(), gx.requires_grad or gy2.requires_grad))
+        finally:
+            RS.enabled = True
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
 def test_filtered_lrelu_matches_composition(native, dtype):
     FL, U = op('filtered_lrelu'), op('upfirdn2d')

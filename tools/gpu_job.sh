@@ -1,11 +1,13 @@
 #!/bin/bash
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd $R
-timeout -k 10 200 python tools/bench_blur_epilogue.py > gpurun_out/r03_blur_epilogue_microbench.log 2>&1; echo rc=$?
-timeout -k 10 600 python bench.py > gpurun_out/r03_bench_b32_final.json 2> gpurun_out/r03_bench_b32_final.err || exit 1
+timeout -k 10 400 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "residual_tail" > gpurun_out/wg_tests.log 2>&1; echo rc=$?; tail -12 gpurun_out/wg_tests.log | cut -c1-250
+for v in 1 0 1; do
+MG_FUSED_RESIDUAL=$v timeout -k 10 500 python bench.py --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/r3_bench_b32_residual$v.json 2> gpurun_out/r3_bench_b32_residual$v.err || exit 1
 python - <<P
 import json
-d = json.loads(open('gpurun_out/r03_bench_b32_final.json').read().strip().splitlines()[-1])
-print('default', d['ms_per_step'], d['host_enqueue_ms_per_step'], d['value'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline']['all_kernels']['upfirdn2d_nhwc'])
+d = json.loads(open('gpurun_out/r3_bench_b32_residual$v.json').read().strip().splitlines()[-1])
+ak = d['roofline']['all_kernels']
+print('residual=$v', d['ms_per_step'], d['value'], ak.get('residual'), ak.get('bias_act'))
 P
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/r3_gpu_tests.log 2>&1; echo rc=$?; tail -3 gpurun_out/r3_gpu_tests.log | cut -c1-220
+done
