@@ -28,6 +28,9 @@ struct SepArgs {
     // up only: the input is a VIRTUAL reflect-padded image (torch.nn.functional.pad(mode='reflect')) of the sw x sh source at x:
     // ih / iw are the padded sizes, (rx0, ry0) the left / top margins.  sw = 0: x is the input itself.
     int sw, sh, rx0, ry0;
+    // up with a reflect-padded input only: device float[4] = (mx0, my0, mx1, my1), the margins actually NEEDED around the source (<= rx0 ... by
+    // construction); output tiles that lie entirely outside the up-sampled needed region are not computed (NULL: everything is)
+    const float* win;
     // workgroup -> tile: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2; tile W of the list
     // (x fastest, then y, then plane) is given to workgroup (W % chunk) * 8 + W / chunk, so that every XCD works through one
     // contiguous eighth of the list and the aprons shared by neighbouring tiles are L2 hits (PMC before: the input was fetched
@@ -63,6 +66,13 @@ __global__ void __launch_bounds__(256) sep12_up2_kernel(SepArgs a)
     uint32_t tile_x, tile_y, plane;
     if (!tile_of_workgroup(a, tile_x, tile_y, plane)) return;          // the whole workgroup, before any barrier
     const int ox0 = (int)tile_x * 64, oy0 = (int)tile_y * 64;
+    if (a.win) {
+        // the consumer (the affine warp) reads inside the image padded by ceil(win) only: in up-sampled coordinates of THIS (larger) padding
+        // that is [2 (r0 - m0), 2 (r0 + size + m1)) per axis; two samples of slack for the warp's bilinear footprint (uniform test)
+        const int mx0 = (int)ceilf(a.win[0]), my0 = (int)ceilf(a.win[1]), mx1 = (int)ceilf(a.win[2]), my1 = (int)ceilf(a.win[3]);
+        const int lo_x = 2 * (a.rx0 - mx0) - 2, hi_x = 2 * (a.rx0 + a.sw + mx1) + 2, lo_y = 2 * (a.ry0 - my0) - 2, hi_y = 2 * (a.ry0 + a.sh + my1) + 2;
+        if (ox0 + 64 <= lo_x || ox0 >= hi_x || oy0 + 64 <= lo_y || oy0 >= hi_y) return;
+    }
     const int ix0 = (ox0 >> 1) + a.cx, iy0 = (oy0 >> 1) + a.cy;
     const float* __restrict__ xp = a.x + (size_t)plane * (a.sw ? (size_t)a.sh * a.sw : (size_t)a.ih * a.iw);
 
@@ -212,7 +222,7 @@ extern "C" int mg_upfirdn2d_sep12(const float* x, const float* f, float* y, int6
     MgLaunchScope scope(MG_K_UPFIRDN2D_SEP, st, 4.0 * (double)planes * ((double)ih * iw + (double)oh * ow));
     SepArgs a;
     a.x = x; a.f = f; a.y = y; a.ih = ih; a.iw = iw; a.oh = oh; a.ow = ow; a.flip = flip ? 1 : 0; a.gx = gain_axis; a.gy = gain_axis;
-    a.sw = a.sh = a.rx0 = a.ry0 = 0;
+    a.sw = a.sh = a.rx0 = a.ry0 = 0; a.win = nullptr;
     if (up) {
         const int mx = 1 - padx0, my = 1 - pady0, qx = mx & 1, qy = my & 1;
         a.cx = (mx - qx) >> 1; a.cy = (my - qy) >> 1;
@@ -233,8 +243,20 @@ extern "C" int mg_upfirdn2d_sep12(const float* x, const float* f, float* y, int6
 
 // upsample2d(pad(x, [mx0, mx1, my0, my1], mode='reflect'), f12, up=2) of augment.py:315-317 without the padded image:
 // x [planes, sh, sw] -> y [planes, 2 (sh + my0 + my1), 2 (sw + mx0 + mx1)]; margins in [0, size - 1] (one reflection).
+extern "C" int mg_reflect_pad_upsample12_window(const float* x, const float* f, float* y, int64_t planes, int32_t sh, int32_t sw,
+                                                int32_t mx0, int32_t mx1, int32_t my0, int32_t my1, float gain_axis, const float* window, void* stream);
+
 extern "C" int mg_reflect_pad_upsample12(const float* x, const float* f, float* y, int64_t planes, int32_t sh, int32_t sw,
                                          int32_t mx0, int32_t mx1, int32_t my0, int32_t my1, float gain_axis, void* stream)
+{
+    return mg_reflect_pad_upsample12_window(x, f, y, planes, sh, sw, mx0, mx1, my0, my1, gain_axis, nullptr, stream);
+}
+
+// ... with `window` (device float[4] = mx0, my0, mx1, my1 as computed on the device, each <= the padding above): the margins the consumer
+// needs.  Output tiles outside the needed region are left UNWRITTEN -- the padding can then be a bound known to the host (a recorded HIP graph
+// cannot read the data-dependent margin back) at the cost of the needed region only.
+extern "C" int mg_reflect_pad_upsample12_window(const float* x, const float* f, float* y, int64_t planes, int32_t sh, int32_t sw,
+                                                int32_t mx0, int32_t mx1, int32_t my0, int32_t my1, float gain_axis, const float* window, void* stream)
 {
     MG_REQUIRE(x && f && y, "reflect_pad_upsample12: x, f and y must reside on the device");
     MG_REQUIRE(planes >= 0 && planes <= 65535 && sh >= 1 && sw >= 1, "reflect_pad_upsample12: bad shape");
@@ -248,7 +270,7 @@ extern "C" int mg_reflect_pad_upsample12(const float* x, const float* f, float* 
     MgLaunchScope scope(MG_K_UPFIRDN2D_SEP, st, 4.0 * (double)planes * ((double)sh * sw + 4.0 * (double)ih * iw));
     SepArgs a;
     a.x = x; a.f = f; a.y = y; a.ih = (int)ih; a.iw = (int)iw; a.oh = (int)(2 * ih); a.ow = (int)(2 * iw); a.flip = 0; a.gx = gain_axis; a.gy = gain_axis;
-    a.sw = sw; a.sh = sh; a.rx0 = mx0; a.ry0 = my0;
+    a.sw = sw; a.sh = sh; a.rx0 = mx0; a.ry0 = my0; a.win = window;
     // upsample2d's padding for 12 taps: pad0 = (12 + 2 - 1) / 2 = 6 -> q = (1 - 6) & 1 = 1, c = (1 - 6 - 1) >> 1 = -3
     a.cx = -3; a.cy = -3;
     set_tiles(a, 64, 64, planes);

@@ -124,6 +124,7 @@ def _declare(L):
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_float, c_void_p]
     L.mg_upfirdn2d_sep12.argtypes = [c_void_p, c_void_p, c_void_p, c_i64] + [c_i32] * 8 + [c_float, c_void_p]
     L.mg_reflect_pad_upsample12.argtypes = [c_void_p, c_void_p, c_void_p, c_i64] + [c_i32] * 6 + [c_float, c_void_p]
+    L.mg_reflect_pad_upsample12_window.argtypes = [c_void_p, c_void_p, c_void_p, c_i64] + [c_i32] * 6 + [c_float, c_void_p, c_void_p]
     L.mg_mbstd_fwd.argtypes = [c_void_p, c_void_p] + [c_i32] * 5 + [c_void_p]
     L.mg_mbstd_bwd.argtypes = [c_void_p, c_void_p, c_void_p] + [c_i32] * 5 + [c_void_p]
     L.mg_demod_fwd.argtypes = [c_void_p] * 4 + [c_i32] * 5 + [c_void_p]
@@ -162,7 +163,7 @@ def _declare(L):
     for name in ('mg_upfirdn2d', 'mg_upfirdn2d_index_table', 'mg_bias_act', 'mg_fma_bias_act',
                  'mg_alpha_composite_fwd', 'mg_alpha_composite_bwd', 'mg_translate_sample_fwd',
                  'mg_translate_sample_bwd_input', 'mg_translate_sample_bwd_shift', 'mg_filtered_lrelu', 'mg_bwd_fused',
-                 'mg_fma_bias_act_nhwc', 'mg_bwd_fused_nhwc', 'mg_affine_warp_fwd', 'mg_affine_warp_bwd', 'mg_channel_mix', 'mg_demod_fwd', 'mg_demod_bwd', 'mg_stats_accumulate', 'mg_ada_params', 'mg_modconv3x3_c64', 'mg_upfirdn2d_sep12', 'mg_reflect_pad_upsample12', 'mg_mbstd_fwd', 'mg_mbstd_bwd', 'mg_torgb_nhwc_fwd', 'mg_torgb_nhwc_bwd', 'mg_torgb_bwd_finish', 'mg_bwd_fused_nhwc_y', 'mg_upfirdn2d_epilogue', 'mg_wgrad3x3_c64', 'mg_fromrgb_nhwc_fwd', 'mg_fromrgb_nhwc_bwd', 'mg_residual_bias_act_fwd', 'mg_residual_bias_act_bwd',
+                 'mg_fma_bias_act_nhwc', 'mg_bwd_fused_nhwc', 'mg_affine_warp_fwd', 'mg_affine_warp_bwd', 'mg_channel_mix', 'mg_demod_fwd', 'mg_demod_bwd', 'mg_stats_accumulate', 'mg_ada_params', 'mg_modconv3x3_c64', 'mg_upfirdn2d_sep12', 'mg_reflect_pad_upsample12', 'mg_reflect_pad_upsample12_window', 'mg_mbstd_fwd', 'mg_mbstd_bwd', 'mg_torgb_nhwc_fwd', 'mg_torgb_nhwc_bwd', 'mg_torgb_bwd_finish', 'mg_bwd_fused_nhwc_y', 'mg_upfirdn2d_epilogue', 'mg_wgrad3x3_c64', 'mg_fromrgb_nhwc_fwd', 'mg_fromrgb_nhwc_bwd', 'mg_residual_bias_act_fwd', 'mg_residual_bias_act_bwd',
                  'mg_prof_enable', 'mg_prof_collect', 'mg_prof_reset'):
         getattr(L, name).restype = c_int
 

@@ -177,13 +177,14 @@ class _ReflectPadUpsample12(torch.autograd.Function):
     again, which R1 needs (it differentiates the discriminator input twice through the augmentation pipe)."""
 
     @staticmethod
-    def forward(ctx, x, f, mx0, mx1, my0, my1):
+    def forward(ctx, x, f, mx0, mx1, my0, my1, window=None):
         from .. import native
         n, c, sh, sw = x.shape
         y = torch.empty([n, c, 2 * (sh + my0 + my1), 2 * (sw + mx0 + mx1)], dtype=x.dtype, device=x.device)
         with native.guard(x.device):
-            native.check(native.lib().mg_reflect_pad_upsample12(native.ptr(x), native.ptr(f), native.ptr(y), n * c, sh, sw, mx0, mx1, my0, my1,
-                                                                2.0, native.stream_ptr(x.device)))
+            # window: device float32[4] (mx0, my0, mx1, my1) of the margins the consumer really needs -- tiles outside stay unwritten
+            native.check(native.lib().mg_reflect_pad_upsample12_window(native.ptr(x), native.ptr(f), native.ptr(y), n * c, sh, sw, mx0, mx1, my0, my1,
+                                                                       2.0, native.ptr(window), native.stream_ptr(x.device)))
         ctx.save_for_backward(x, f)
         ctx.margins = (mx0, mx1, my0, my1)
         return y
@@ -196,17 +197,22 @@ class _ReflectPadUpsample12(torch.autograd.Function):
             grad_cls = _upfirdn2d_cuda(up=1, down=2, padding=[5, 5, 5, 5], flip_filter=True, gain=4)     # Upfirdn2dCuda.backward's arithmetic for up=2, pad (6, 5)
             gp = grad_cls.apply(dy, f) if torch.is_grad_enabled() else grad_cls.forward(_NoCtx, dy, f)
             dx = torch.ops.aten.reflection_pad2d_backward(gp, x, list(ctx.margins))
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
-def reflect_pad_upsample2d(x, f, margins):
+def reflect_pad_upsample2d(x, f, margins, window=None):
     """``upsample2d(torch.nn.functional.pad(x, margins, mode='reflect'), f, up=2)`` (training/augment.py:315-317); margins =
-    [left, right, top, bottom].  One launch for the 12-tap filter on dense float32 device tensors, the two ops otherwise."""
+    [left, right, top, bottom].  ``window`` (device float32[4]: left, top, right, bottom margins as computed on the device, each <= the
+    padding): only the part of the result a consumer with those margins reads is computed, the rest is left uninitialised -- for callers that
+    must pad by a host-known bound (a recorded HIP graph cannot read the data-dependent margin back).  One launch for the 12-tap filter on dense float32 device tensors, the two ops otherwise."""
     mx0, mx1, my0, my1 = (int(m) for m in margins)
     if (sep12_enabled and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and f.ndim == 1 and f.numel() == 12 and f.is_cuda
             and f.dtype == torch.float32 and 0 < x.shape[0] * x.shape[1] <= 65535 and min(mx0, mx1, my0, my1) >= 0
             and max(mx0, mx1) < x.shape[3] and max(my0, my1) < x.shape[2] and _init()):
-        return _ReflectPadUpsample12.apply(x, f.contiguous(), mx0, mx1, my0, my1)
+        if window is not None:
+            window = window.detach().to(torch.float32).contiguous()
+            assert window.numel() == 4 and window.device == x.device
+        return _ReflectPadUpsample12.apply(x, f.contiguous(), mx0, mx1, my0, my1, window)
     x = torch.nn.functional.pad(input=x, pad=[mx0, mx1, my0, my1], mode='reflect')
     return upsample2d(x=x, f=f, up=2)
 

@@ -32,6 +32,7 @@ from ..torch_utils.ops import grid_sample_gradfix  # noqa: F401  (reference impo
 from ..torch_utils.ops import upfirdn2d
 
 fixed_margin = False          # True: never read the padding margin back to the host (see module docstring)
+device_window = True          # with fixed_margin: the pad + upsample pass computes only the region the device-side margin asks for
 side_stream_margin = False    # True: compute transform parameters + margin on a side stream, wait only for that
 fused_params = True            # GPU, no debug_percentile: transform parameters from ONE native launch (ops/ada_params.py)
 _side_streams = dict()
@@ -370,7 +371,9 @@ class AugmentPipe(torch.nn.Module):
                 margins = tuple(int(v) for v in margin.ceil().to(torch.int32).tolist())   # the one host sync
             mx0, my0, mx1, my1 = margins
             # reflect-pad + x2 upsample with the 12-tap symlet (:315-317): one native launch, the padded image is never written
-            images = upfirdn2d.reflect_pad_upsample2d(images, self.Hz_geom, [mx0, mx1, my0, my1])
+            # fixed margin: the padding is the clamp bound, the WORK the margin computed on the device (`margin` never leaves it)
+            images = upfirdn2d.reflect_pad_upsample2d(images, self.Hz_geom, [mx0, mx1, my0, my1],
+                                                      window=margin if (fixed_margin and device_window and margin is not None and images.is_cuda) else None)
             if theta is None:
                 # sample on the output lattice: left @ G_inv @ right
                 left, right, shape = self._sampling_factors(n, ch, height, width, margins)

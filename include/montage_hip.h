@@ -125,6 +125,11 @@ int mg_upfirdn2d_sep12(const float* x, const float* f, float* y, int64_t planes,
  * float32 dense, margins in [0, size - 1].                                                                          */
 int mg_reflect_pad_upsample12(const float* x, const float* f, float* y, int64_t planes, int32_t src_h, int32_t src_w,
                               int32_t mx0, int32_t mx1, int32_t my0, int32_t my1, float gain_axis, void* stream);
+/* ... with `window` = device float[4] (mx0, my0, mx1, my1 as computed on the device, each <= the padding given here): output tiles outside the
+ * up-sampled region the consumer needs are left unwritten, so the padding can be a host-known bound (HIP-graph recording) at the cost of the
+ * needed region.  NULL: as above. */
+int mg_reflect_pad_upsample12_window(const float* x, const float* f, float* y, int64_t planes, int32_t src_h, int32_t src_w,
+                                     int32_t mx0, int32_t mx1, int32_t my0, int32_t my1, float gain_axis, const float* window, void* stream);
 
 /* Integer index path only (the part that must be bit exact): for each output
  * coordinate o in [0, out_size) writes {in0, count, filter0} as computed on the

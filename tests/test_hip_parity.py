@@ -1394,6 +1394,36 @@ def test_augment_pipe_native_params_statistics(native):
             AU.fixed_margin = False
 
 
+def test_fixed_margin_device_window_computes_what_is_read(native):
+    """augment.fixed_margin pads by the clamp bound (a recorded HIP graph cannot read the data-dependent margin back); with
+    `device_window` the pad + upsample pass computes only the tiles the margin COMPUTED ON THE DEVICE asks for and leaves the rest of
+    its (9x larger) output unwritten.  Same images (bit for bit) and image gradients as computing everything -- with the allocator's
+    free memory poisoned with NaN first, so that a read of an unwritten tile would show."""
+    AU = importlib.import_module(f'{PKG}.training.augment')
+    pipe = AU.AugmentPipe(**AU.augpipe_specs['bgc']).to(DEV)
+    pipe.p.copy_(torch.as_tensor(1.0))
+    x = (torch.rand([6, 4, 64, 64], device=DEV, generator=torch.Generator(device=DEV).manual_seed(4)) * 2 - 1)
+    AU.fixed_margin = True
+    try:
+        res = []
+        for window in (True, False):
+            AU.device_window = window
+            poison = torch.full([64 * 1024 * 1024], float('nan'), device=DEV)        # 256 MB of NaN back into the caching allocator
+            del poison
+            torch.manual_seed(21)
+            xx = x.clone().requires_grad_(True)
+            y = pipe(xx)
+            gx, = torch.autograd.grad([(y * torch.linspace(-1, 1, y.numel(), device=DEV).reshape(y.shape)).sum()], [xx])
+            res.append((y.detach(), gx))
+        assert bool(torch.isfinite(res[0][0]).all()) and bool(torch.isfinite(res[0][1]).all())
+        assert torch.equal(res[0][0], res[1][0])
+        # (the image gradient passes through float atomics of the warp's adjoint: equal up to their order)
+        np.testing.assert_allclose(res[0][1].cpu().numpy(), res[1][1].cpu().numpy(), rtol=0, atol=2e-6)
+        assert float((res[0][0] - x).abs().mean()) > 1e-2                            # the pipe did transform
+    finally:
+        AU.fixed_margin, AU.device_window = False, True
+
+
 # --------------------------------------------------------------------------------------------
 # fused modulated 3x3 convolution on the matrix cores (csrc/modconv.hip)
 
